@@ -1,0 +1,126 @@
+"""Seeded parity cases shared by the golden generator and the test-suite.
+
+Every input is re-derived from integers below, so the golden files only carry
+reference OUTPUTS.  Names follow BASELINE.json's configs where they apply:
+cfg2 = 4 cameras 640x512 / 48^3 grid, cfg3 = 12 cameras 1280x1024 / 64^3 grid.
+"""
+import torch
+import torch.nn.functional as F
+
+from jarvis_hybridnet_amd import synthetic as S
+
+# tag -> (model_size, joints, batch, image side, weight seed, input seed)
+EFFTRACK_CASES = {
+    "cfg1_small_j12": ("small", 12, 1, 256, 1, 0),      # BASELINE configs[0]
+    "small_j1_b2": ("small", 1, 2, 256, 2, 3),
+    "small_j23_b2": ("small", 23, 2, 256, 4, 5),
+    "small_j23_128": ("small", 23, 3, 128, 4, 6),
+    "medium_j23": ("medium", 23, 1, 256, 7, 8),
+    "large_j23": ("large", 23, 1, 192, 9, 10),
+}
+
+# tag -> (C, J, G, spacing, bbox, W, H, focal, seed)
+REPRO_CASES = {
+    "tiny": (2, 3, 8, 4, 28, 160, 128, 300.0, 11),
+    "cfg2": (4, 23, 48, 2, 256, 640, 512, 900.0, 12),
+    "cfg3": (12, 23, 64, 2, 256, 1280, 1024, 1800.0, 13),
+    "cfg5": (16, 30, 96, 2, 256, 1280, 1024, 1800.0, 14),
+}
+
+# tag -> (J, G, weight seed, input seed)
+V2V_CASES = {
+    "j3_g16": (3, 16, 20, 21),
+    "j23_g48": (23, 48, 22, 23),
+    "j23_g64": (23, 64, 22, 24),
+}
+
+# tag -> (C, W, H, focal, seed)
+GEOM_CASES = {
+    "c4": (4, 640, 512, 900.0, 30),
+    "c12": (12, 1280, 1024, 1800.0, 31),
+}
+
+HYBRID_CASES = {
+    "cfg2": dict(C=4, J=23, roi=96, spacing=2, bbox=256, W=640, H=512,
+                 focal=900.0, wseed=40, fseed=41),
+    "cfg3": dict(C=12, J=23, roi=128, spacing=2, bbox=256, W=1280, H=1024,
+                 focal=1800.0, wseed=40, fseed=42),
+}
+
+PREDICTOR_CASES = {
+    "cfg2": dict(C=4, J=23, roi=96, spacing=2, bbox=256, center_size=256,
+                 W=640, H=512, focal=900.0, cseed=50, hseed=51, fseed=53),
+    "cfg3": dict(C=12, J=23, roi=128, spacing=2, bbox=256, center_size=256,
+                 W=1280, H=1024, focal=1800.0, cseed=50, hseed=51, fseed=52),
+    "cfg2_none": dict(C=4, J=23, roi=96, spacing=2, bbox=256, center_size=256,
+                      W=640, H=512, focal=900.0, cseed=50, hseed=51, fseed=53,
+                      deconv_std=0.05, expect_none=True),
+}
+
+
+def efftrack_input(batch, hw, seed):
+    return torch.randn(batch, 3, hw, hw, generator=torch.Generator().manual_seed(seed))
+
+
+def v2v_input(J, G, seed):
+    """Non-negative sparse-ish volume in the 0..1 range V2V sees (vol/255)."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(1, J, G, G, G, generator=g)
+    return (x * x * x).contiguous()
+
+
+def subject_geometry(C, W, H, focal, bbox, seed):
+    """A true subject centre, its integer crop centres (clamped like
+    jarvis3D.py:161-166) and the calibration."""
+    cam, intr, dist = S.ring_calibration(C, W, H, focal)
+    g = torch.Generator().manual_seed(seed)
+    centre = (torch.rand(3, generator=g) * 160 - 80)
+    uv = torch.from_numpy(S.project(centre[None].double().numpy(), cam, intr, dist))[:, 0]
+    hw = bbox // 2
+    chm = uv.int()
+    chm[:, 0] = chm[:, 0].clamp(min(hw, W - hw), max(hw, W - hw))
+    chm[:, 1] = chm[:, 1].clamp(min(hw, H - hw), max(hw, H - hw))
+    return cam, intr, dist, centre, chm
+
+
+def repro_inputs(tag):
+    C, J, G, spacing, bbox, W, H, focal, seed = REPRO_CASES[tag]
+    cam, intr, dist, centre, chm = subject_geometry(C, W, H, focal, bbox, seed)
+    hm = S.smooth_heatmaps(C, J, bbox // 2, seed + 100)
+    hm_pad = F.pad(hm, [1, 1, 1, 1])[None]
+    return dict(hm_pad=hm_pad.contiguous(), center3d=centre.int()[None],
+                center_hm=chm[None], cam=cam[None], intr=intr[None], dist=dist[None])
+
+
+def geom_inputs(tag):
+    C, W, H, focal, seed = GEOM_CASES[tag]
+    cam, intr, dist = S.ring_calibration(C, W, H, focal)
+    g = torch.Generator().manual_seed(seed)
+    p3d = (torch.rand(1, 3, generator=g) * 200 - 100)
+    uv = torch.from_numpy(S.project(p3d.double().numpy(), cam, intr, dist))[:, 0].float()
+    uv = uv + torch.randn(uv.shape, generator=g) * 2.0      # detection noise
+    maxvals = (0.3 + 0.7 * torch.rand(C, 1, 1, generator=g))
+    return uv.transpose(0, 1).contiguous(), maxvals, p3d
+
+
+def hybrid_inputs(tag):
+    c = HYBRID_CASES[tag]
+    cam, intr, dist, centre, chm = subject_geometry(c["C"], c["W"], c["H"],
+                                                    c["focal"], c["bbox"], c["fseed"])
+    sd = S.hybridnet_weights("small", c["J"], c["wseed"])
+    g = torch.Generator().manual_seed(c["fseed"])
+    crops = torch.randn(1, c["C"], 3, c["bbox"], c["bbox"], generator=g)
+    return dict(sd_hybrid=sd, crops=crops, center_hm=chm[None],
+                center3d=centre.int()[None], cam=cam[None], intr=intr[None],
+                dist=dist[None])
+
+
+def predictor_inputs(tag):
+    c = PREDICTOR_CASES[tag]
+    calib = S.ring_calibration(c["C"], c["W"], c["H"], c["focal"])
+    std = c.get("deconv_std", 1.2)
+    sd_c = S.efficienttrack_weights("small", 1, c["cseed"], deconv_std=std)
+    sd_h = S.hybridnet_weights("small", c["J"], c["hseed"])
+    imgs, joints, centre = S.blob_frames(calib, c["W"], c["H"], c["J"], c["fseed"])
+    return dict(sd_center=sd_c, sd_hybrid=sd_h, imgs=imgs, cam=calib[0],
+                intr=calib[1], dist=calib[2], joints=joints, centre=centre)

@@ -1,0 +1,115 @@
+"""CPU: the oracle reproduces the reference's golden outputs bit-for-bit.
+
+The golden vectors were produced by tests/golden/make_golden.py from the
+imported upstream reference (torch 2.10 CPU, fp32).  Bit equality is asserted
+because the oracle issues the same ATen ops in the same order; if this suite is
+ever run on a different torch build the arithmetic of conv/IN kernels may
+differ in the last bits, hence the fallback tolerance documented below.
+"""
+import os
+
+import pytest
+import torch
+
+from oracle import hybridnet_oracle as O
+from jarvis_hybridnet_amd import synthetic as S
+from tests import cases
+from tests.util import check_summary
+
+torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+# exact on the image the fixtures were made with; a foreign CPU may pick other
+# oneDNN kernels, so allow float32 round-off there (never needed so far).
+EXACT = os.environ.get("JH_GOLDEN_TOL", "0") == "0"
+TOL = {} if EXACT else dict(rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("tag", list(cases.EFFTRACK_CASES))
+def test_efficienttrack(golden, tag):
+    size, J, N, hw, wseed, xseed = cases.EFFTRACK_CASES[tag]
+    sd = S.efficienttrack_weights(size, J, wseed)
+    x = cases.efftrack_input(N, hw, xseed)
+    with torch.no_grad():
+        r1, r2 = O.efficienttrack_forward(sd, x, size)
+    g = golden("efficienttrack")
+    check_summary(g, tag + ".res1", r1, **TOL)
+    check_summary(g, tag + ".res2", r2, **TOL)
+
+
+@pytest.mark.parametrize("tag", ["tiny", "cfg2", "cfg3"])
+def test_reprojection(golden, tag):
+    C, J, G, spacing = cases.REPRO_CASES[tag][:4]
+    inp = cases.repro_inputs(tag)
+    vol, idx = O.reprojection_forward(inp["hm_pad"], inp["center3d"], inp["center_hm"],
+                                      inp["cam"], inp["intr"], inp["dist"],
+                                      G * spacing, spacing, chunk=5, return_idx=True)
+    g = golden("reprojection")
+    check_summary(g, tag + ".idx", idx)            # integer path: always exact
+    check_summary(g, tag + ".vol", vol, **TOL)
+
+
+@pytest.mark.parametrize("tag", list(cases.V2V_CASES))
+def test_v2v_and_tail(golden, tag):
+    J, G, wseed, xseed = cases.V2V_CASES[tag]
+    sd = S.v2v_weights(J, wseed)
+    x = cases.v2v_input(J, G, xseed)
+    with torch.no_grad():
+        out = O.v2v_forward(sd, x)
+        center = torch.tensor([[35, -58, 549]], dtype=torch.int32)
+        fin, pts, conf = O.softargmax_tail(out, center, G * 2, 2)
+    g = golden("v2v")
+    check_summary(g, tag + ".out", out, **TOL)
+    check_summary(g, tag + ".points", pts, **TOL)
+    check_summary(g, tag + ".conf", conf, **TOL)
+    check_summary(g, tag + ".final", fin, **TOL)
+
+
+@pytest.mark.parametrize("tag", list(cases.GEOM_CASES))
+def test_geometry(golden, tag):
+    C, W, H, focal, seed = cases.GEOM_CASES[tag]
+    cam, intr, dist = S.ring_calibration(C, W, H, focal)
+    pts2d, maxvals, p3d = cases.geom_inputs(tag)
+    g = golden("geometry")
+    rec = O.reconstruct_point(pts2d, maxvals, cam, intr, dist)
+    rep = O.reproject_point(p3d, cam, intr, dist)
+    check_summary(g, tag + ".reconstruct", rec, **TOL)
+    check_summary(g, tag + ".reproject", rep, **TOL)
+    # sanity of the fixture itself: triangulating noisy projections of p3d
+    assert (rec - p3d[0]).abs().max() < 5.0
+
+
+@pytest.mark.parametrize("tag", ["cfg2"])
+def test_hybridnet(golden, tag):
+    c = cases.HYBRID_CASES[tag]
+    inp = cases.hybrid_inputs(tag)
+    with torch.no_grad():
+        fin, hm, pts, conf = O.hybridnet_forward(
+            inp["sd_hybrid"], "small", c["roi"], c["spacing"], inp["crops"],
+            inp["center_hm"], inp["center3d"], inp["cam"], inp["intr"], inp["dist"], chunk=5)
+    g = golden("hybridnet")
+    check_summary(g, tag + ".points3D", pts, **TOL)
+    check_summary(g, tag + ".confidences", conf, **TOL)
+    check_summary(g, tag + ".heatmap_final", fin, **TOL)
+    check_summary(g, tag + ".heatmaps_padded", hm, **TOL)
+
+
+@pytest.mark.parametrize("tag", ["cfg2", "cfg2_none"])
+def test_predictor(golden, tag):
+    c = cases.PREDICTOR_CASES[tag]
+    inp = cases.predictor_inputs(tag)
+    inter = {}
+    with torch.no_grad():
+        pts, conf = O.predictor3d_forward(
+            inp["sd_center"], inp["sd_hybrid"], inp["imgs"], inp["cam"], inp["intr"],
+            inp["dist"], center_size=c["center_size"], bbox=c["bbox"],
+            roi_cube_size=c["roi"], grid_spacing=c["spacing"], mean=S.MEAN, std=S.STD,
+            chunk=5, intermediates=inter)
+    g = golden("predictor")
+    assert int(g[tag + ".n_detect"]) == inter["n_detect"]
+    if c.get("expect_none"):
+        assert pts is None and conf is None
+        return
+    check_summary(g, tag + ".preds", inter["preds"])
+    check_summary(g, tag + ".center_hm", inter["center_hm"])
+    check_summary(g, tag + ".center3d", inter["center3d"], **TOL)
+    check_summary(g, tag + ".points3D", pts, **TOL)
+    check_summary(g, tag + ".confidences", conf, **TOL)

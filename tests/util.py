@@ -1,0 +1,29 @@
+"""Helpers shared by the parity tests."""
+import numpy as np
+import torch
+
+
+def check_summary(g, name, t, rtol=0.0, atol=0.0):
+    """Compare tensor `t` with a golden entry written by make_golden.put():
+    either the full tensor or strided samples + float64 checksums."""
+    if name in g:
+        ref = torch.from_numpy(g[name])
+        assert tuple(ref.shape) == tuple(t.shape), (name, ref.shape, t.shape)
+        if rtol == 0 and atol == 0:
+            assert torch.equal(ref, t.to(ref.dtype)), name
+        else:
+            torch.testing.assert_close(t.to(ref.dtype), ref, rtol=rtol, atol=atol)
+        return
+    shape = tuple(int(v) for v in g[name + ".shape"])
+    assert shape == tuple(t.shape), (name, shape, tuple(t.shape))
+    flat = t.detach().double().reshape(-1).numpy()
+    step = int(g[name + ".step"])
+    sample = g[name + ".sample"].astype(np.float64)
+    if rtol == 0 and atol == 0:
+        assert np.array_equal(flat[::step], sample), name
+        assert flat.sum() == float(g[name + ".sum"]), name
+        assert np.abs(flat).sum() == float(g[name + ".abssum"]), name
+    else:
+        np.testing.assert_allclose(flat[::step], sample, rtol=rtol, atol=atol)
+        scale = float(g[name + ".abssum"])
+        assert abs(flat.sum() - float(g[name + ".sum"])) <= rtol * scale + atol * flat.size
