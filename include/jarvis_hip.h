@@ -1,0 +1,168 @@
+/* libjarvis_hip.so -- C ABI of the MI355X (gfx950) implementation of the
+ * JARVIS-HybridNet multi-view inference hot path.
+ *
+ * This is the drop-in boundary: plain C, raw device pointers, explicit shapes,
+ * an explicit hipStream_t (passed as void*), int status (0 = OK; the message of
+ * the last failure on the calling thread is returned by jh_last_error()).
+ * No function synchronises the device or allocates caller-visible memory during
+ * a forward call, so a whole forward may be captured into a hipGraph.
+ *
+ * The library occupies the seam the reference itself uses for acceleration:
+ * JarvisPredictor3D replaces three sub-networks by compiled modules after
+ * torch.ops.load_library(<native .so>)  (jarvis/prediction/jarvis3D.py:50-69,
+ * 72-125, binary converters under libs/).  Each entry point below cites the
+ * reference function it replaces.
+ *
+ * Conventions: all tensors fp32 unless noted; "dev" = device pointer, "host" =
+ * host pointer; NCHW / NCDHW = the reference's layouts; calibration in the
+ * reference's transposed storage (jarvis/utils/reprojection.py:33-39):
+ * cameraMatrices (C,4,3), intrinsicMatrices (C,3,3) with the principal point in
+ * row 2, distortionCoefficients (C,1,5) with k1,k2 first.
+ */
+#ifndef JARVIS_HIP_H
+#define JARVIS_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JH_ABI_VERSION 1
+
+const char* jh_last_error(void);
+int jh_abi_version(void);
+
+/* ---- parameters: a state dict in the reference's .pth key layout ----------
+ * Replaces torch.load + load_state_dict of jarvis/hybridnet/hybridnet.py:84-97
+ * and jarvis/efficienttrack/efficienttrack.py:90-113 on the native side. */
+typedef struct jh_params jh_params;
+int jh_params_create(jh_params** out);
+int jh_params_set(jh_params* p, const char* key, const float* host, int64_t numel);
+void jh_params_destroy(jh_params* p);
+
+/* ---- EfficientTrackBackbone.forward  (jarvis/efficienttrack/model.py:114-130)
+ * model_size: 0 small, 1 medium, 2 large.  Built for a fixed (N,3,H,W) input.
+ * forward: x (N,3,H,W) NCHW dev -> res2 (N,J,H/2,W/2) NCHW dev.  The res1
+ * branch (final_conv1) is dead on the inference path and is not computed. */
+typedef struct jh_efftrack jh_efftrack;
+int jh_efftrack_create(const jh_params* p, const char* prefix, int model_size, int joints, int n,
+                       int h, int w, jh_efftrack** out);
+int jh_efftrack_forward(jh_efftrack* net, const float* x_dev, float* res2_dev, void* stream);
+int64_t jh_efftrack_launches(const jh_efftrack* net);
+void jh_efftrack_destroy(jh_efftrack* net);
+
+/* ---- V2VNet.forward  (jarvis/hybridnet/v2vnet.py:98-102)
+ * x (T,J,G,G,G) NCDHW dev -> y (T,J,G/2,G/2,G/2) NCDHW dev. */
+typedef struct jh_v2v jh_v2v;
+int jh_v2v_create(const jh_params* p, const char* prefix, int joints, int t, int g, jh_v2v** out);
+int jh_v2v_forward(jh_v2v* net, const float* x_dev, float* y_dev, void* stream);
+void jh_v2v_destroy(jh_v2v* net);
+
+/* ---- ReprojectionLayer.forward  (jarvis/hybridnet/repro_layer.py:110-119)
+ * heatmaps_padded (1,C,J,hs,hs) NCHW dev, center3d (3) int32 dev, center_hm
+ * (C,2) int32 dev, calibration dev -> vol (1,J,G,G,G) NCDHW dev (NOT divided by
+ * 255, like the reference layer).  idx_dev (C,G,G,G) int32 optional (may be
+ * NULL): the reference's integer gather index (reprojectPoints, :40-85). */
+int jh_reproject_forward(const float* heatmaps_padded_dev, int cams, int joints, int hs,
+                         const int32_t* center3d_dev, const int32_t* center_hm_dev,
+                         const float* cam_dev, const float* intr_dev, const float* dist_dev,
+                         int grid_size, float grid_spacing, float* vol_dev, int32_t* idx_dev,
+                         void* stream);
+
+/* ---- soft-argmax tail of HybridNetBackbone.forward (hybridnet/model.py:73-88)
+ * v2v_out (T,J,Gh,Gh,Gh) NCDHW dev, center3d (T,3) int32 dev -> points (T,J,3),
+ * conf (T,J), heatmap_final (T,J,Gh,Gh,Gh) optional (NULL to skip). */
+int jh_softargmax(const float* v2v_out_dev, int t, int joints, int gh, float grid_spacing,
+                  float roi_cube_size, const int32_t* center3d_dev, float* heatmap_final_dev,
+                  float* points_dev, float* conf_dev, void* stream);
+
+/* ---- ReprojectionTool  (jarvis/utils/reprojection.py:49-90)
+ * reproject: points (P,3) dev -> uv (C,P,2) dev.
+ * reconstruct: points2d (2,C) dev (pixels), maxvals (C) dev -> point3d (3) dev. */
+int jh_reproject_point(const float* points_dev, int npoints, int cams, const float* cam_dev,
+                       const float* intr_dev, const float* dist_dev, float* uv_dev, void* stream);
+int jh_reconstruct_point(const float* points2d_dev, const float* maxvals_dev, int cams,
+                         const float* cam_dev, const float* intr_dev, const float* dist_dev,
+                         float* point3d_dev, void* stream);
+
+/* ---- JarvisPredictor3D  (jarvis/prediction/jarvis3D.py:20-46,129-190) and
+ * HybridNetBackbone.forward (jarvis/hybridnet/model.py:53-90).
+ * One object owns both 2D networks, the V2V network and every intermediate.
+ * time_batch T independent multi-view frames are processed per call (the
+ * reference's batch-1 call is T = 1).  cam_lo/cam_n select the cameras whose 2D
+ * work this process owns (camera sharding across GPUs); the 3D stage always
+ * sees all cameras. */
+typedef struct jh_predictor jh_predictor;
+typedef struct {
+  int32_t num_cameras, num_joints;
+  int32_t center_size;        /* CENTERDETECT.IMAGE_SIZE */
+  int32_t bbox;               /* KEYPOINTDETECT.BOUNDING_BOX_SIZE */
+  float roi_cube_size;        /* HYBRIDNET.ROI_CUBE_SIZE (mm) */
+  float grid_spacing;         /* HYBRIDNET.GRID_SPACING (mm) */
+  int32_t center_model, kp_model;   /* 0 small, 1 medium, 2 large */
+  int32_t img_h, img_w;
+  int32_t time_batch;
+  int32_t cam_lo, cam_n;
+  float mean[3], std[3];      /* DATASET.MEAN / DATASET.STD */
+} jh_predictor_config;
+
+/* center_params may be NULL (HybridNetBackbone-only use). */
+int jh_predictor_create(const jh_params* center_params, const jh_params* hybrid_params,
+                        const jh_predictor_config* cfg, jh_predictor** out);
+void jh_predictor_destroy(jh_predictor* pr);
+int64_t jh_predictor_launches(const jh_predictor* pr);
+int64_t jh_predictor_device_bytes(const jh_predictor* pr);
+
+/* calibration of all cameras (device pointers, copied). */
+int jh_predictor_set_calibration(jh_predictor* pr, const float* cam_dev, const float* intr_dev,
+                                 const float* dist_dev, void* stream);
+
+/* Stage 1 (jarvis3D.py:135-155): resize + normalise + CenterDetect + argmax for
+ * the owned cameras.  frames (T,cam_n,3,H,W) dev -> det (T,cam_n,3) = (x, y,
+ * raw maxval) dev. */
+int jh_predictor_stage_center(jh_predictor* pr, const float* frames_dev, float* det_dev,
+                              void* stream);
+/* Stage 2 (jarvis3D.py:157-178 + model.py:55-63): det_all (T,C,3) of ALL cameras
+ * -> triangulate, project, crop + normalise + KeypointDetect for the owned
+ * cameras -> heat (T,cam_n,B/2,B/2,Jp) channel-last dev, Jp = joints rounded up
+ * to 8. */
+int jh_predictor_stage_keypoints(jh_predictor* pr, const float* frames_dev,
+                                 const float* det_all_dev, float* heat_dev, void* stream);
+/* Stage 3 (model.py:65-88): heat_all (T,C,B/2,B/2,Jp) of ALL cameras -> points
+ * (T,J,3), conf (T,J), valid (T) int32 (0 = fewer than two cameras saw the
+ * subject: the reference returns (None, None), jarvis3D.py:187-190). */
+int jh_predictor_stage_3d(jh_predictor* pr, const float* heat_all_dev, float* points_dev,
+                          float* conf_dev, int32_t* valid_dev, void* stream);
+/* All three stages for cam_lo = 0, cam_n = num_cameras. */
+int jh_predictor_forward(jh_predictor* pr, const float* frames_dev, float* points_dev,
+                         float* conf_dev, int32_t* valid_dev, void* stream);
+/* Integer path of the last call, for parity tests: center3d float (T,3),
+ * center3d int (T,3), center_hm (T,C,2), det (T,C,3).  Any pointer may be NULL. */
+int jh_predictor_debug(jh_predictor* pr, float* center3d_f_dev, int32_t* center3d_i_dev,
+                       int32_t* center_hm_dev, float* det_dev, void* stream);
+
+/* HybridNetBackbone.forward: crops (T,C,3,B,B) normalised NCHW dev, center_hm
+ * (T,C,2) int32, center3d (T,3) int32 -> heatmap_final (T,J,Gh,Gh,Gh) optional,
+ * heatmaps_padded (T,C,J,hs,hs) optional, points (T,J,3), conf (T,J). */
+int jh_predictor_hybridnet_forward(jh_predictor* pr, const float* crops_dev,
+                                   const int32_t* center_hm_dev, const int32_t* center3d_dev,
+                                   float* heatmap_final_dev, float* heatmaps_padded_dev,
+                                   float* points_dev, float* conf_dev, void* stream);
+
+/* ---- single-operator entry points (building blocks; used by the unit tests)
+ * conv: x (N,Cin,[D,]H,W) -> y; weights/bias are HOST pointers in torch layout
+ * ((Cout,Cin,k..) or, transposed, (Cin,Cout,k..)); kind 0 = conv (k, stride,
+ * pad), 1 = ConvTranspose2d k4 s2 p1, 2 = ConvTranspose3d k2 s2.  When
+ * norm_act >= 0 the InstanceNorm (+ activation 0 none / 1 relu / 2 silu) that
+ * follows the conv in the networks is applied from the fused statistics. */
+int jh_op_conv(int nd, int kind, int k, int stride, int pad, int cin, int cout,
+               const float* w_host, const float* b_host, const float* x_dev, int n, int d, int h,
+               int w, const float* gate_dev, int norm_act, float* y_dev, void* stream);
+/* depthwise k x k stride 1: x (N,C,H,W), w_host (C,1,k,k) -> y. */
+int jh_op_depthwise(int k, int c, const float* w_host, const float* x_dev, int n, int h, int w,
+                    int norm_act, float* y_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JARVIS_HIP_H */

@@ -1,0 +1,135 @@
+"""ctypes binding of libjarvis_hip.so (the C ABI in include/jarvis_hip.h).
+
+There is deliberately no fallback: if the shared library is missing or a call
+fails, a RuntimeError is raised.  PyTorch is used only as the owner of device
+memory and streams -- every pointer crossing this boundary is a raw address.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libjarvis_hip.so")
+_lib = None
+
+c_void_p, c_int, c_float, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
+c_char_p = ctypes.c_char_p
+
+
+class PredictorConfig(ctypes.Structure):
+    _fields_ = [("num_cameras", ctypes.c_int32), ("num_joints", ctypes.c_int32),
+                ("center_size", ctypes.c_int32), ("bbox", ctypes.c_int32),
+                ("roi_cube_size", c_float), ("grid_spacing", c_float),
+                ("center_model", ctypes.c_int32), ("kp_model", ctypes.c_int32),
+                ("img_h", ctypes.c_int32), ("img_w", ctypes.c_int32),
+                ("time_batch", ctypes.c_int32), ("cam_lo", ctypes.c_int32),
+                ("cam_n", ctypes.c_int32), ("mean", c_float * 3), ("std", c_float * 3)]
+
+
+_SIGS = {
+    "jh_last_error": (c_char_p, []),
+    "jh_abi_version": (c_int, []),
+    "jh_params_create": (c_int, [ctypes.POINTER(c_void_p)]),
+    "jh_params_set": (c_int, [c_void_p, c_char_p, c_void_p, c_int64]),
+    "jh_params_destroy": (None, [c_void_p]),
+    "jh_efftrack_create": (c_int, [c_void_p, c_char_p, c_int, c_int, c_int, c_int, c_int,
+                                   ctypes.POINTER(c_void_p)]),
+    "jh_efftrack_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "jh_efftrack_launches": (c_int64, [c_void_p]),
+    "jh_efftrack_destroy": (None, [c_void_p]),
+    "jh_v2v_create": (c_int, [c_void_p, c_char_p, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "jh_v2v_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "jh_v2v_destroy": (None, [c_void_p]),
+    "jh_reproject_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p,
+                                     c_void_p]),
+    "jh_softargmax": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p,
+                              c_void_p, c_void_p, c_void_p]),
+    "jh_reproject_point": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p]),
+    "jh_reconstruct_point": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p]),
+    "jh_predictor_create": (c_int, [c_void_p, c_void_p, ctypes.POINTER(PredictorConfig),
+                                    ctypes.POINTER(c_void_p)]),
+    "jh_predictor_destroy": (None, [c_void_p]),
+    "jh_predictor_launches": (c_int64, [c_void_p]),
+    "jh_predictor_device_bytes": (c_int64, [c_void_p]),
+    "jh_predictor_set_calibration": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "jh_predictor_stage_center": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "jh_predictor_stage_keypoints": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "jh_predictor_stage_3d": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "jh_predictor_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "jh_predictor_debug": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "jh_predictor_hybridnet_forward": (c_int, [c_void_p] * 9),
+    "jh_op_conv": (c_int, [c_int] * 7 + [c_void_p, c_void_p, c_void_p] + [c_int] * 4 +
+                   [c_void_p, c_int, c_void_p, c_void_p]),
+    "jh_op_depthwise": (c_int, [c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                c_void_p, c_void_p]),
+}
+
+
+def symbols():
+    """Names of every entry point include/jarvis_hip.h declares."""
+    return sorted(_SIGS)
+
+
+def lib():
+    """Load the shared library once; raise if it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise RuntimeError(
+                "jarvis_hybridnet_amd: %s is missing -- build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
+                "There is no CPU fallback." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(handle, name)          # AttributeError if the .so lacks a symbol
+            fn.restype, fn.argtypes = res, args
+        if handle.jh_abi_version() != 1:
+            raise RuntimeError("libjarvis_hip.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("libjarvis_hip: " + lib().jh_last_error().decode())
+
+
+def ptr(t):
+    """Raw address of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "tensor must be contiguous"
+    return t.data_ptr()
+
+
+def dev(t, dtype=torch.float32):
+    """Contiguous CUDA tensor of the given dtype (the API's input convention)."""
+    if not t.is_cuda:
+        raise RuntimeError("jarvis_hybridnet_amd needs CUDA (HIP) tensors; got a CPU tensor")
+    return t.to(dtype).contiguous()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Params:
+    """A state dict handed to the native side (host copies, reference key layout)."""
+
+    def __init__(self, state_dict):
+        self.handle = c_void_p()
+        check(lib().jh_params_create(ctypes.byref(self.handle)))
+        self._keep = []
+        for key, t in state_dict.items():
+            h = t.detach().to("cpu", torch.float32).contiguous()
+            self._keep.append(h)
+            check(lib().jh_params_set(self.handle, key.encode(), h.data_ptr(), h.numel()))
+
+    def __del__(self):
+        if getattr(self, "handle", None) and _lib is not None:
+            _lib.jh_params_destroy(self.handle)
+            self.handle = None

@@ -1,0 +1,45 @@
+"""Parameter trees with the reference's state-dict key layout."""
+import torch
+import torch.nn as nn
+
+
+def register_params(root, spec, init="zeros"):
+    """Create nested parameter holders so that root.state_dict() has exactly
+    the keys / shapes / order of `spec` (list of (dotted key, shape))."""
+    for key, shape in spec:
+        parts = key.split(".")
+        mod = root
+        for name in parts[:-1]:
+            if name not in mod._modules:
+                mod.add_module(name, nn.Module())
+            mod = mod._modules[name]
+        t = torch.ones(shape) if len(shape) == 1 and parts[-1] != "bias" and init == "ones1d" \
+            else torch.zeros(shape)
+        mod.register_parameter(parts[-1], nn.Parameter(t, requires_grad=False))
+
+
+def flat_state(module, prefix=""):
+    """{key: tensor} of a module with keys relative to the module."""
+    return {prefix + k: v for k, v in module.state_dict().items()}
+
+
+class NativeModule(nn.Module):
+    """nn.Module whose forward runs in libjarvis_hip; native plans are rebuilt
+    whenever parameters are (re)loaded or the input shape changes."""
+
+    def __init__(self):
+        super().__init__()
+        self._plans = {}
+
+    def _invalidate(self):
+        for plan in self._plans.values():
+            plan.close()
+        self._plans = {}
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        res = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._invalidate()
+        return res
+
+    def _apply(self, fn, *a, **k):          # .cuda() / .to(): parameters move, plans stay valid
+        return super()._apply(fn, *a, **k)

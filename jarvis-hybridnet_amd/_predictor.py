@@ -1,0 +1,90 @@
+"""Python handle of the native predictor (jh_predictor_* in include/jarvis_hip.h)."""
+import ctypes
+
+import torch
+
+from . import _native as N
+from . import arch
+
+
+class NativePredictor:
+    """Owns the launch plans of CenterDetect, KeypointDetect and V2V plus all
+    intermediates for `time_batch` multi-view frames of a fixed size."""
+
+    def __init__(self, center_state, hybrid_state, *, num_cameras, num_joints, center_size, bbox,
+                 roi_cube_size, grid_spacing, img_h, img_w, mean, std, center_model="small",
+                 kp_model="small", time_batch=1, cam_lo=0, cam_n=None):
+        cam_n = num_cameras if cam_n is None else cam_n
+        cfg = N.PredictorConfig(
+            num_cameras, num_joints, center_size, bbox, float(roi_cube_size), float(grid_spacing),
+            arch.SIZE_IDS[center_model], arch.SIZE_IDS[kp_model], img_h, img_w, time_batch, cam_lo,
+            cam_n, (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std))
+        self.cfg = cfg
+        self.T, self.C, self.Cloc, self.J = time_batch, num_cameras, cam_n, num_joints
+        self.Jp = (num_joints + 7) // 8 * 8
+        self.Hh = bbox // 2
+        self.handle = ctypes.c_void_p()
+        pc = N.Params(center_state) if center_state is not None else None
+        ph = N.Params(hybrid_state)
+        N.check(N.lib().jh_predictor_create(pc.handle if pc else None, ph.handle,
+                                            ctypes.byref(cfg), ctypes.byref(self.handle)))
+        self.launches = N.lib().jh_predictor_launches(self.handle)
+        self.device_bytes = N.lib().jh_predictor_device_bytes(self.handle)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            N.lib().jh_predictor_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+    # ---- calibration -----------------------------------------------------
+    def set_calibration(self, cam, intr, dist):
+        N.check(N.lib().jh_predictor_set_calibration(
+            self.handle, N.ptr(N.dev(cam)), N.ptr(N.dev(intr)), N.ptr(N.dev(dist)), N.stream()))
+
+    # ---- single-GPU forward ----------------------------------------------
+    def forward(self, frames, out=None):
+        """frames (T,C,3,H,W) -> points (T,J,3), conf (T,J), valid (T) int32."""
+        dev = frames.device
+        if out is None:
+            out = (torch.empty((self.T, self.J, 3), device=dev),
+                   torch.empty((self.T, self.J), device=dev),
+                   torch.empty((self.T,), device=dev, dtype=torch.int32))
+        N.check(N.lib().jh_predictor_forward(self.handle, N.ptr(frames), N.ptr(out[0]),
+                                             N.ptr(out[1]), N.ptr(out[2]), N.stream()))
+        return out
+
+    # ---- camera-sharded stages -------------------------------------------
+    def stage_center(self, frames, det):
+        N.check(N.lib().jh_predictor_stage_center(self.handle, N.ptr(frames), N.ptr(det), N.stream()))
+
+    def stage_keypoints(self, frames, det_all, heat):
+        N.check(N.lib().jh_predictor_stage_keypoints(self.handle, N.ptr(frames), N.ptr(det_all),
+                                                     N.ptr(heat), N.stream()))
+
+    def stage_3d(self, heat_all, points, conf, valid):
+        N.check(N.lib().jh_predictor_stage_3d(self.handle, N.ptr(heat_all), N.ptr(points),
+                                              N.ptr(conf), N.ptr(valid), N.stream()))
+
+    def debug(self, device):
+        c3f = torch.empty((self.T, 3), device=device)
+        c3i = torch.empty((self.T, 3), device=device, dtype=torch.int32)
+        chm = torch.empty((self.T, self.C, 2), device=device, dtype=torch.int32)
+        det = torch.empty((self.T, self.C, 3), device=device)
+        N.check(N.lib().jh_predictor_debug(self.handle, N.ptr(c3f), N.ptr(c3i), N.ptr(chm),
+                                           N.ptr(det), N.stream()))
+        return dict(center3d=c3f, center3d_int=c3i, center_hm=chm, det=det)
+
+    def hybridnet_forward(self, crops, center_hm, center3d, want_final=True, want_padded=True):
+        dev = crops.device
+        Gh = int(self.cfg.roi_cube_size / self.cfg.grid_spacing) // 2
+        hs = self.Hh + 2
+        final = torch.empty((self.T, self.J, Gh, Gh, Gh), device=dev) if want_final else None
+        padded = torch.empty((self.T, self.C, self.J, hs, hs), device=dev) if want_padded else None
+        pts = torch.empty((self.T, self.J, 3), device=dev)
+        conf = torch.empty((self.T, self.J), device=dev)
+        N.check(N.lib().jh_predictor_hybridnet_forward(
+            self.handle, N.ptr(crops), N.ptr(center_hm), N.ptr(center3d), N.ptr(final),
+            N.ptr(padded), N.ptr(pts), N.ptr(conf), N.stream()))
+        return final, padded, pts, conf

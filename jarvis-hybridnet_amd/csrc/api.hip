@@ -1,0 +1,420 @@
+// C ABI of libjarvis_hip.so (declarations + reference citations: include/jarvis_hip.h)
+#include <cstring>
+#include <memory>
+#include "../../include/jarvis_hip.h"
+#include "nets.h"
+
+namespace jh {
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+}  // namespace jh
+
+using namespace jh;
+
+struct jh_params { ParamMap map; };
+struct jh_efftrack { EffTrackPlan plan; };
+struct jh_v2v { V2VPlan plan; };
+
+namespace {
+
+// RAII device scratch for the non-pipelined (test / API-parity) entry points.
+struct Scratch {
+  std::vector<void*> ptrs;
+  ~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
+  int get(void** p, size_t bytes) {
+    JH_CHECK_HIP(hipMalloc(p, bytes));
+    ptrs.push_back(*p);
+    return 0;
+  }
+  int act(int N, int D, int H, int W, int C, Act* a) {
+    a->N = N; a->D = D; a->H = H; a->W = W; a->C = C; a->Cp = cpad(C);
+    return get(reinterpret_cast<void**>(&a->p), a->bytes());
+  }
+};
+
+// (T,C) channel-last heatmaps [N][Hh][Hh][Jp] -> padded NCHW (N,J,hs,hs)
+__global__ void export_padded_kernel(const float* __restrict__ heat, float* __restrict__ out, int N,
+                                     int J, int Jp, int Hh) {
+  const int hs = Hh + 2;
+  const size_t total = (size_t)N * J * hs * hs;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % hs), y = (int)((i / hs) % hs);
+    const int j = (int)((i / ((size_t)hs * hs)) % J);
+    const size_t n = i / ((size_t)hs * hs * J);
+    float v = 0.f;
+    if (x >= 1 && y >= 1 && x <= Hh && y <= Hh)
+      v = heat[((n * Hh + (y - 1)) * Hh + (x - 1)) * Jp + j];
+    out[i] = v;
+  }
+}
+
+__global__ void pack_det_kernel(const float* __restrict__ pts2d, const float* __restrict__ maxvals,
+                                float* __restrict__ det, int C) {
+  const int c = threadIdx.x;
+  if (c < C) {
+    det[c * 3 + 0] = pts2d[c];
+    det[c * 3 + 1] = pts2d[C + c];
+    det[c * 3 + 2] = maxvals[c];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* jh_last_error(void) { return g_err.c_str(); }
+int jh_abi_version(void) { return JH_ABI_VERSION; }
+
+int jh_params_create(jh_params** out) {
+  *out = new jh_params();
+  return 0;
+}
+int jh_params_set(jh_params* p, const char* key, const float* host, int64_t numel) {
+  JH_REQUIRE(p && key && host && numel >= 0, "bad argument");
+  p->map[key] = std::vector<float>(host, host + numel);
+  return 0;
+}
+void jh_params_destroy(jh_params* p) { delete p; }
+
+// ---------------------------------------------------------------- EfficientTrack
+int jh_efftrack_create(const jh_params* p, const char* prefix, int model_size, int joints, int n,
+                       int h, int w, jh_efftrack** out) {
+  JH_REQUIRE(p && out, "bad argument");
+  std::unique_ptr<jh_efftrack> net(new jh_efftrack());
+  if (net->plan.build(p->map, prefix ? prefix : "", model_size, joints, n, h, w)) return 1;
+  *out = net.release();
+  return 0;
+}
+int jh_efftrack_forward(jh_efftrack* net, const float* x_dev, float* res2_dev, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (launch_to_channel_last(x_dev, net->plan.input, s)) return 1;
+  if (net->plan.run(s)) return 1;
+  return launch_from_channel_last(net->plan.heat, res2_dev, s);
+}
+int64_t jh_efftrack_launches(const jh_efftrack* net) { return (int64_t)net->plan.launches(); }
+void jh_efftrack_destroy(jh_efftrack* net) { delete net; }
+
+// --------------------------------------------------------------------------- V2V
+int jh_v2v_create(const jh_params* p, const char* prefix, int joints, int t, int g, jh_v2v** out) {
+  JH_REQUIRE(p && out, "bad argument");
+  std::unique_ptr<jh_v2v> net(new jh_v2v());
+  if (net->plan.build(p->map, prefix ? prefix : "", joints, t, g)) return 1;
+  *out = net.release();
+  return 0;
+}
+int jh_v2v_forward(jh_v2v* net, const float* x_dev, float* y_dev, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (launch_to_channel_last(x_dev, net->plan.input, s)) return 1;
+  if (net->plan.run(s)) return 1;
+  return launch_from_channel_last(net->plan.output, y_dev, s);
+}
+void jh_v2v_destroy(jh_v2v* net) { delete net; }
+
+// ------------------------------------------------------------------ reprojection
+int jh_reproject_forward(const float* heatmaps_padded_dev, int cams, int joints, int hs,
+                         const int32_t* center3d_dev, const int32_t* center_hm_dev,
+                         const float* cam_dev, const float* intr_dev, const float* dist_dev,
+                         int grid_size, float grid_spacing, float* vol_dev, int32_t* idx_dev,
+                         void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  Scratch sc;
+  Act heat, vol;
+  if (sc.act(cams, 1, hs, hs, joints, &heat)) return 1;
+  if (sc.act(1, grid_size, grid_size, grid_size, joints, &vol)) return 1;
+  float2* coarse;
+  const int gh = grid_size / 2;
+  if (sc.get(reinterpret_cast<void**>(&coarse), (size_t)cams * gh * gh * gh * sizeof(float2))) return 1;
+  if (launch_to_channel_last(heatmaps_padded_dev, heat, s)) return 1;
+  if (launch_reproject(cam_dev, intr_dev, dist_dev, center3d_dev, center_hm_dev, heat.p, coarse,
+                       vol.p, idx_dev, 1, cams, grid_size, grid_spacing, hs, heat.Cp, /*heat_pad=*/1,
+                       /*div255=*/0, s)) return 1;
+  if (launch_from_channel_last(vol, vol_dev, s)) return 1;
+  JH_CHECK_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+int jh_softargmax(const float* v2v_out_dev, int t, int joints, int gh, float grid_spacing,
+                  float roi_cube_size, const int32_t* center3d_dev, float* heatmap_final_dev,
+                  float* points_dev, float* conf_dev, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  Scratch sc;
+  Act x;
+  if (sc.act(t, gh, gh, gh, joints, &x)) return 1;
+  double* partial; int* pmax;
+  if (sc.get(reinterpret_cast<void**>(&partial), (size_t)t * x.Cp * 4 * sizeof(double))) return 1;
+  if (sc.get(reinterpret_cast<void**>(&pmax), (size_t)t * x.Cp * sizeof(int))) return 1;
+  if (launch_to_channel_last(v2v_out_dev, x, s)) return 1;
+  if (launch_softargmax(x.p, center3d_dev, partial, pmax, points_dev, conf_dev, heatmap_final_dev, t,
+                        joints, x.Cp, gh, grid_spacing, roi_cube_size, s)) return 1;
+  JH_CHECK_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+int jh_reproject_point(const float* points_dev, int npoints, int cams, const float* cam_dev,
+                       const float* intr_dev, const float* dist_dev, float* uv_dev, void* stream) {
+  return launch_project_points(points_dev, cam_dev, intr_dev, dist_dev, uv_dev, npoints, cams,
+                               static_cast<hipStream_t>(stream));
+}
+
+int jh_reconstruct_point(const float* points2d_dev, const float* maxvals_dev, int cams,
+                         const float* cam_dev, const float* intr_dev, const float* dist_dev,
+                         float* point3d_dev, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  JH_REQUIRE(cams <= 64, "at most 64 cameras");
+  Scratch sc;
+  float* det; int *c3i, *chm, *valid;
+  if (sc.get(reinterpret_cast<void**>(&det), (size_t)cams * 3 * sizeof(float))) return 1;
+  if (sc.get(reinterpret_cast<void**>(&c3i), 3 * sizeof(int))) return 1;
+  if (sc.get(reinterpret_cast<void**>(&chm), (size_t)cams * 2 * sizeof(int))) return 1;
+  if (sc.get(reinterpret_cast<void**>(&valid), sizeof(int))) return 1;
+  hipLaunchKernelGGL(pack_det_kernel, dim3(1), dim3(64), 0, s, points2d_dev, maxvals_dev, det, cams);
+  if (launch_triangulate(det, cam_dev, intr_dev, dist_dev, point3d_dev, c3i, chm, valid, 1, cams,
+                         1.f, 1.f, 1.f, 0, 1 << 20, 1 << 20, s)) return 1;
+  JH_CHECK_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------- predictor
+struct jh_predictor {
+  jh_predictor_config cfg{};
+  int T = 0, C = 0, Cloc = 0, J = 0, Jp = 0, B = 0, Hh = 0, G = 0, Gh = 0, hs = 0;
+  std::unique_ptr<EffTrackPlan> center, kp;
+  std::unique_ptr<V2VPlan> v2v;
+  Scratch mem;
+  float *cam = nullptr, *intr = nullptr, *dist = nullptr;
+  float *det_all = nullptr, *c3f = nullptr;
+  int *c3i = nullptr, *chm = nullptr, *valid = nullptr;
+  float2* coarse = nullptr;
+  double* sa_partial = nullptr;
+  int* sa_max = nullptr;
+
+  int run_3d(const float* heat_all, float* heatmap_final, float* points, float* conf,
+             hipStream_t s) {
+    if (launch_reproject(cam, intr, dist, c3i, chm, heat_all, coarse, v2v->input.p, nullptr, T, C,
+                         G, cfg.grid_spacing, hs, Jp, /*heat_pad=*/0, /*div255=*/1, s)) return 1;
+    if (v2v->run(s)) return 1;
+    return launch_softargmax(v2v->output.p, c3i, sa_partial, sa_max, points, conf, heatmap_final, T,
+                             J, Jp, Gh, cfg.grid_spacing, cfg.roi_cube_size, s);
+  }
+};
+
+extern "C" {
+
+int jh_predictor_create(const jh_params* center_params, const jh_params* hybrid_params,
+                        const jh_predictor_config* cfg, jh_predictor** out) {
+  JH_REQUIRE(hybrid_params && cfg && out, "bad argument");
+  std::unique_ptr<jh_predictor> pr(new jh_predictor());
+  pr->cfg = *cfg;
+  pr->T = cfg->time_batch; pr->C = cfg->num_cameras; pr->Cloc = cfg->cam_n;
+  pr->J = cfg->num_joints; pr->Jp = cpad(cfg->num_joints);
+  pr->B = cfg->bbox; pr->Hh = cfg->bbox / 2; pr->hs = cfg->bbox / 2 + 2;
+  pr->G = (int)(cfg->roi_cube_size / cfg->grid_spacing);
+  pr->Gh = pr->G / 2;
+  JH_REQUIRE(pr->T >= 1 && pr->C >= 1 && pr->C <= 64, "time batch / camera count");
+  JH_REQUIRE(cfg->cam_lo >= 0 && cfg->cam_n >= 1 && cfg->cam_lo + cfg->cam_n <= pr->C, "camera range");
+  JH_REQUIRE(pr->G % 4 == 0, "ROI_CUBE_SIZE / GRID_SPACING must be a multiple of 4");
+  const int N = pr->T * pr->Cloc;
+  if (center_params) {
+    pr->center.reset(new EffTrackPlan());
+    if (pr->center->build(center_params->map, "", cfg->center_model, 1, N, cfg->center_size,
+                          cfg->center_size)) return 1;
+  }
+  pr->kp.reset(new EffTrackPlan());
+  if (pr->kp->build(hybrid_params->map, "effTrack.", cfg->kp_model, pr->J, N, pr->B, pr->B)) return 1;
+  pr->v2v.reset(new V2VPlan());
+  if (pr->v2v->build(hybrid_params->map, "v2vNet.", pr->J, pr->T, pr->G)) return 1;
+  auto& m = pr->mem;
+  const int T = pr->T, C = pr->C;
+  if (m.get(reinterpret_cast<void**>(&pr->cam), (size_t)C * 12 * sizeof(float))) return 1;
+  if (m.get(reinterpret_cast<void**>(&pr->intr), (size_t)C * 9 * sizeof(float))) return 1;
+  if (m.get(reinterpret_cast<void**>(&pr->dist), (size_t)C * 5 * sizeof(float))) return 1;
+  if (m.get(reinterpret_cast<void**>(&pr->det_all), (size_t)T * C * 3 * sizeof(float))) return 1;
+  if (m.get(reinterpret_cast<void**>(&pr->c3f), (size_t)T * 3 * sizeof(float))) return 1;
+  if (m.get(reinterpret_cast<void**>(&pr->c3i), (size_t)T * 3 * sizeof(int))) return 1;
+  if (m.get(reinterpret_cast<void**>(&pr->chm), (size_t)T * C * 2 * sizeof(int))) return 1;
+  if (m.get(reinterpret_cast<void**>(&pr->valid), (size_t)T * sizeof(int))) return 1;
+  if (m.get(reinterpret_cast<void**>(&pr->coarse),
+            (size_t)T * C * pr->Gh * pr->Gh * pr->Gh * sizeof(float2))) return 1;
+  if (m.get(reinterpret_cast<void**>(&pr->sa_partial), (size_t)T * pr->Jp * 4 * sizeof(double))) return 1;
+  if (m.get(reinterpret_cast<void**>(&pr->sa_max), (size_t)T * pr->Jp * sizeof(int))) return 1;
+  JH_CHECK_HIP(hipMemset(pr->valid, 0, (size_t)T * sizeof(int)));
+  JH_CHECK_HIP(hipDeviceSynchronize());
+  *out = pr.release();
+  return 0;
+}
+
+void jh_predictor_destroy(jh_predictor* pr) { delete pr; }
+
+int64_t jh_predictor_launches(const jh_predictor* pr) {
+  return (int64_t)((pr->center ? pr->center->launches() : 0) + pr->kp->launches() +
+                   pr->v2v->launches());
+}
+int64_t jh_predictor_device_bytes(const jh_predictor* pr) {
+  return (int64_t)((pr->center ? pr->center->device_bytes() : 0) + pr->kp->device_bytes() +
+                   pr->v2v->device_bytes());
+}
+
+int jh_predictor_set_calibration(jh_predictor* pr, const float* cam_dev, const float* intr_dev,
+                                 const float* dist_dev, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  JH_CHECK_HIP(hipMemcpyAsync(pr->cam, cam_dev, (size_t)pr->C * 12 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  JH_CHECK_HIP(hipMemcpyAsync(pr->intr, intr_dev, (size_t)pr->C * 9 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  JH_CHECK_HIP(hipMemcpyAsync(pr->dist, dist_dev, (size_t)pr->C * 5 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
+int jh_predictor_stage_center(jh_predictor* pr, const float* frames_dev, float* det_dev,
+                              void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  JH_REQUIRE(pr->center, "predictor was created without CenterDetect weights");
+  const int N = pr->T * pr->Cloc, S = pr->cfg.center_size;
+  if (launch_preprocess_resize(frames_dev, pr->center->input.p, N, pr->cfg.img_h, pr->cfg.img_w, S,
+                               pr->cfg.mean, pr->cfg.std, s)) return 1;
+  if (pr->center->run(s)) return 1;
+  const Act& h = pr->center->heat;
+  return launch_center_argmax(h.p, det_dev, N, h.H, h.W, h.Cp, s);
+}
+
+int jh_predictor_stage_keypoints(jh_predictor* pr, const float* frames_dev,
+                                 const float* det_all_dev, float* heat_dev, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const auto& c = pr->cfg;
+  // preds * (downsampling_scale * 2), jarvis3D.py:138-141,158-160
+  const float sx2 = (float)((double)c.img_w / (double)c.center_size) * 2.f;
+  const float sy2 = (float)((double)c.img_h / (double)c.center_size) * 2.f;
+  if (launch_triangulate(det_all_dev, pr->cam, pr->intr, pr->dist, pr->c3f, pr->c3i, pr->chm,
+                         pr->valid, pr->T, pr->C, sx2, sy2, 255.f, pr->B / 2, c.img_w, c.img_h, s))
+    return 1;
+  if (det_all_dev != pr->det_all)
+    JH_CHECK_HIP(hipMemcpyAsync(pr->det_all, det_all_dev, (size_t)pr->T * pr->C * 3 * sizeof(float),
+                                hipMemcpyDeviceToDevice, s));
+  if (launch_preprocess_crop(frames_dev, pr->chm, pr->kp->input.p, pr->T, pr->Cloc, pr->C, c.cam_lo,
+                             c.img_h, c.img_w, pr->B, c.mean, c.std, s)) return 1;
+  if (pr->kp->run(s)) return 1;
+  if (heat_dev && heat_dev != pr->kp->heat.p)
+    JH_CHECK_HIP(hipMemcpyAsync(heat_dev, pr->kp->heat.p, pr->kp->heat.bytes(),
+                                hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
+int jh_predictor_stage_3d(jh_predictor* pr, const float* heat_all_dev, float* points_dev,
+                          float* conf_dev, int32_t* valid_dev, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (pr->run_3d(heat_all_dev, nullptr, points_dev, conf_dev, s)) return 1;
+  if (valid_dev)
+    JH_CHECK_HIP(hipMemcpyAsync(valid_dev, pr->valid, (size_t)pr->T * sizeof(int),
+                                hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
+int jh_predictor_forward(jh_predictor* pr, const float* frames_dev, float* points_dev,
+                         float* conf_dev, int32_t* valid_dev, void* stream) {
+  JH_REQUIRE(pr->Cloc == pr->C && pr->cfg.cam_lo == 0, "forward needs all cameras local");
+  if (jh_predictor_stage_center(pr, frames_dev, pr->det_all, stream)) return 1;
+  if (jh_predictor_stage_keypoints(pr, frames_dev, pr->det_all, nullptr, stream)) return 1;
+  return jh_predictor_stage_3d(pr, pr->kp->heat.p, points_dev, conf_dev, valid_dev, stream);
+}
+
+int jh_predictor_debug(jh_predictor* pr, float* center3d_f_dev, int32_t* center3d_i_dev,
+                       int32_t* center_hm_dev, float* det_dev, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t T = pr->T, C = pr->C;
+  if (center3d_f_dev) JH_CHECK_HIP(hipMemcpyAsync(center3d_f_dev, pr->c3f, T * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (center3d_i_dev) JH_CHECK_HIP(hipMemcpyAsync(center3d_i_dev, pr->c3i, T * 3 * sizeof(int), hipMemcpyDeviceToDevice, s));
+  if (center_hm_dev) JH_CHECK_HIP(hipMemcpyAsync(center_hm_dev, pr->chm, T * C * 2 * sizeof(int), hipMemcpyDeviceToDevice, s));
+  if (det_dev) JH_CHECK_HIP(hipMemcpyAsync(det_dev, pr->det_all, T * C * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
+int jh_predictor_hybridnet_forward(jh_predictor* pr, const float* crops_dev,
+                                   const int32_t* center_hm_dev, const int32_t* center3d_dev,
+                                   float* heatmap_final_dev, float* heatmaps_padded_dev,
+                                   float* points_dev, float* conf_dev, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  JH_REQUIRE(pr->Cloc == pr->C, "hybridnet_forward needs all cameras local");
+  JH_CHECK_HIP(hipMemcpyAsync(pr->chm, center_hm_dev, (size_t)pr->T * pr->C * 2 * sizeof(int), hipMemcpyDeviceToDevice, s));
+  JH_CHECK_HIP(hipMemcpyAsync(pr->c3i, center3d_dev, (size_t)pr->T * 3 * sizeof(int), hipMemcpyDeviceToDevice, s));
+  if (launch_to_channel_last(crops_dev, pr->kp->input, s)) return 1;
+  if (pr->kp->run(s)) return 1;
+  if (heatmaps_padded_dev) {
+    const Act& h = pr->kp->heat;
+    const size_t total = (size_t)h.N * pr->J * pr->hs * pr->hs;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(export_padded_kernel, dim3(blocks), dim3(256), 0, s, h.p, heatmaps_padded_dev,
+                       h.N, pr->J, h.Cp, pr->Hh);
+    JH_CHECK_HIP(hipGetLastError());
+  }
+  return pr->run_3d(pr->kp->heat.p, heatmap_final_dev, points_dev, conf_dev, s);
+}
+
+// -------------------------------------------------------- single-operator tests
+int jh_op_conv(int nd, int kind, int k, int stride, int pad, int cin, int cout,
+               const float* w_host, const float* b_host, const float* x_dev, int n, int d, int h,
+               int w, const float* gate_dev, int norm_act, float* y_dev, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  ConvDesc desc = kind == 0 ? conv_desc(nd, k, stride, pad, cin, cout)
+                            : (kind == 1 ? deconv2d_k4s2p1_desc(cin, cout) : deconv3d_k2s2_desc(cin, cout));
+  Scratch sc;
+  Act x, y;
+  if (nd == 2) d = 1;
+  if (sc.act(n, d, h, w, cin, &x)) return 1;
+  int Do, Ho, Wo;
+  conv_out_shape(desc, d, h, w, &Do, &Ho, &Wo);
+  if (sc.act(n, Do, Ho, Wo, cout, &y)) return 1;
+  JH_CHECK_HIP(hipMemsetAsync(y.p, 0, y.bytes(), s));
+  ConvWeights cw;
+  if (pack_conv_weights(desc, w_host, b_host, kind != 0, &cw)) return 1;
+  double* stats = nullptr;
+  float* gate_p = nullptr;
+  int rc = 0;
+  do {
+    if (norm_act >= 0) {
+      if ((rc = sc.get(reinterpret_cast<void**>(&stats), (size_t)n * y.Cp * 2 * sizeof(double)))) break;
+      if (hipMemsetAsync(stats, 0, (size_t)n * y.Cp * 2 * sizeof(double), s) != hipSuccess) { rc = 1; break; }
+    }
+    if (gate_dev) {   // (N,Cin) -> padded (N,Cin_p)
+      if ((rc = sc.get(reinterpret_cast<void**>(&gate_p), (size_t)n * x.Cp * sizeof(float)))) break;
+      if (hipMemsetAsync(gate_p, 0, (size_t)n * x.Cp * sizeof(float), s) != hipSuccess) { rc = 1; break; }
+      if (hipMemcpy2DAsync(gate_p, x.Cp * sizeof(float), gate_dev, cin * sizeof(float),
+                           cin * sizeof(float), n, hipMemcpyDeviceToDevice, s) != hipSuccess) { rc = 1; break; }
+    }
+    if ((rc = launch_to_channel_last(x_dev, x, s))) break;
+    if ((rc = launch_conv(desc, cw, x, y, gate_p, stats, s))) break;
+    if (norm_act >= 0 && (rc = launch_norm_apply(y, stats, 1e-5f, norm_act, nullptr, nullptr, y.p, nullptr, s))) break;
+    if ((rc = launch_from_channel_last(y, y_dev, s))) break;
+    if (hipStreamSynchronize(s) != hipSuccess) { set_error("stream sync failed in jh_op_conv"); rc = 1; }
+  } while (0);
+  free_conv_weights(&cw);
+  return rc;
+}
+
+int jh_op_depthwise(int k, int c, const float* w_host, const float* x_dev, int n, int h, int w,
+                    int norm_act, float* y_dev, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  Scratch sc;
+  Act x, y;
+  if (sc.act(n, 1, h, w, c, &x)) return 1;
+  if (sc.act(n, 1, h, w, c, &y)) return 1;
+  std::vector<float> wt((size_t)k * k * x.Cp, 0.f);
+  for (int ch = 0; ch < c; ++ch)
+    for (int t = 0; t < k * k; ++t) wt[(size_t)t * x.Cp + ch] = w_host[(size_t)ch * k * k + t];
+  float* wd; double* stats = nullptr;
+  if (sc.get(reinterpret_cast<void**>(&wd), wt.size() * sizeof(float))) return 1;
+  JH_CHECK_HIP(hipMemcpyAsync(wd, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice, s));
+  if (norm_act >= 0) {
+    if (sc.get(reinterpret_cast<void**>(&stats), (size_t)n * x.Cp * 2 * sizeof(double))) return 1;
+    JH_CHECK_HIP(hipMemsetAsync(stats, 0, (size_t)n * x.Cp * 2 * sizeof(double), s));
+  }
+  if (launch_to_channel_last(x_dev, x, s)) return 1;
+  if (launch_depthwise(x, wd, k, y.p, stats, s)) return 1;
+  if (norm_act >= 0 && launch_norm_apply(y, stats, 1e-5f, norm_act, nullptr, nullptr, y.p, nullptr, s)) return 1;
+  if (launch_from_channel_last(y, y_dev, s)) return 1;
+  JH_CHECK_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+}  // extern "C"

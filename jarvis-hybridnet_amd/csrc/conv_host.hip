@@ -1,0 +1,163 @@
+// Host side of the MFMA convolution: descriptors, weight packing, dispatch.
+#include <vector>
+#include <cstring>
+#include "conv_mfma.h"
+
+namespace jh {
+
+ConvDesc conv_desc(int nd, int k, int stride, int pad, int cin, int cout) {
+  ConvDesc d{};
+  d.nd = nd; d.k = k; d.stride = stride; d.ostride = 1; d.nphase = 1;
+  d.cin = cin; d.cout = cout;
+  d.phase[0].pad[0] = (nd == 3) ? pad : 0;
+  d.phase[0].pad[1] = pad; d.phase[0].pad[2] = pad;
+  d.phase[0].ooff[0] = d.phase[0].ooff[1] = d.phase[0].ooff[2] = 0;
+  return d;
+}
+
+// ConvTranspose2d(k=4, s=2, p=1): output (2y+py, 2x+px) is a 2x2-tap conv of the
+// input; even outputs read inputs {y-1, y} (pad 1), odd outputs {y, y+1} (pad 0).
+ConvDesc deconv2d_k4s2p1_desc(int cin, int cout) {
+  ConvDesc d{};
+  d.nd = 2; d.k = 2; d.stride = 1; d.ostride = 2; d.nphase = 4;
+  d.cin = cin; d.cout = cout;
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px) {
+      ConvPhase& p = d.phase[py * 2 + px];
+      p.pad[0] = 0; p.pad[1] = py ? 0 : 1; p.pad[2] = px ? 0 : 1;
+      p.ooff[0] = 0; p.ooff[1] = py; p.ooff[2] = px;
+    }
+  return d;
+}
+
+// ConvTranspose3d(k=2, s=2, p=0): each of the 8 output parities is a 1x1x1 conv.
+ConvDesc deconv3d_k2s2_desc(int cin, int cout) {
+  ConvDesc d{};
+  d.nd = 3; d.k = 1; d.stride = 1; d.ostride = 2; d.nphase = 8;
+  d.cin = cin; d.cout = cout;
+  for (int p = 0; p < 8; ++p) {
+    d.phase[p].pad[0] = d.phase[p].pad[1] = d.phase[p].pad[2] = 0;
+    d.phase[p].ooff[0] = (p >> 2) & 1; d.phase[p].ooff[1] = (p >> 1) & 1; d.phase[p].ooff[2] = p & 1;
+  }
+  return d;
+}
+
+void conv_out_shape(const ConvDesc& d, int D, int H, int W, int* Do, int* Ho, int* Wo) {
+  if (d.ostride > 1) {          // transposed: every phase produces the input extent
+    *Do = (d.nd == 3) ? D * d.ostride : 1; *Ho = H * d.ostride; *Wo = W * d.ostride;
+    return;
+  }
+  const int kd = (d.nd == 3) ? d.k : 1;
+  *Do = (d.nd == 3) ? (D + 2 * d.phase[0].pad[0] - kd) / d.stride + 1 : 1;
+  *Ho = (H + 2 * d.phase[0].pad[1] - d.k) / d.stride + 1;
+  *Wo = (W + 2 * d.phase[0].pad[2] - d.k) / d.stride + 1;
+}
+
+// Which transposed-conv kernel tap feeds tap t of phase (parity) par for the
+// 2D k4 s2 p1 case: even parity taps {t0: k=3, t1: k=1}, odd {t0: k=2, t1: k=0}.
+static inline int deconv4_tap(int parity, int t) { return parity ? (t == 0 ? 2 : 0) : (t == 0 ? 3 : 1); }
+
+int pack_conv_weights(const ConvDesc& d, const float* w, const float* b, bool transposed,
+                      ConvWeights* out) {
+  const int cin_p = cpad(d.cin);
+  const int cout_p16 = round_up(d.cout, 16);
+  const int kd = (d.nd == 3) ? d.k : 1;
+  const int ntap = kd * d.k * d.k;
+  const int nk8 = cin_p / 8, nb = cout_p16 / 16;
+  const size_t phase_stride = (size_t)ntap * nk8 * nb * 128;
+  std::vector<float> packed(phase_stride * d.nphase, 0.f);
+  // geometry of the source tensor
+  int skd, sk;   // source kernel extents
+  if (d.ostride > 1 && d.nd == 2) { skd = 1; sk = 4; }
+  else if (d.ostride > 1 && d.nd == 3) { skd = 2; sk = 2; }
+  else { skd = kd; sk = d.k; }
+  const size_t sktaps = (size_t)skd * sk * sk;
+  for (int ph = 0; ph < d.nphase; ++ph) {
+    for (int tz = 0; tz < kd; ++tz)
+      for (int ty = 0; ty < d.k; ++ty)
+        for (int tx = 0; tx < d.k; ++tx) {
+          int sz = tz, sy = ty, sx = tx;
+          if (d.ostride > 1 && d.nd == 2) {
+            sy = deconv4_tap(d.phase[ph].ooff[1], ty);
+            sx = deconv4_tap(d.phase[ph].ooff[2], tx);
+          } else if (d.ostride > 1 && d.nd == 3) {
+            sz = d.phase[ph].ooff[0]; sy = d.phase[ph].ooff[1]; sx = d.phase[ph].ooff[2];
+          }
+          const size_t stap = ((size_t)sz * sk + sy) * sk + sx;
+          const int tap = (tz * d.k + ty) * d.k + tx;
+          for (int ci = 0; ci < d.cin; ++ci)
+            for (int co = 0; co < d.cout; ++co) {
+              const float v = transposed ? w[((size_t)ci * d.cout + co) * sktaps + stap]
+                                         : w[((size_t)co * d.cin + ci) * sktaps + stap];
+              const int kc8 = ci / 8, kq = (ci % 8) / 2, j = ci % 2;
+              const int nbk = co / 16, nn = co % 16;
+              const int lane = kq * 16 + nn;
+              packed[ph * phase_stride + (((size_t)tap * nk8 + kc8) * nb + nbk) * 128 + lane * 2 + j] = v;
+            }
+        }
+  }
+  out->cin_p = cin_p; out->cout_p16 = cout_p16; out->phase_stride = phase_stride;
+  JH_CHECK_HIP(hipMalloc(&out->w, packed.size() * sizeof(float)));
+  JH_CHECK_HIP(hipMemcpy(out->w, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+  out->bias = nullptr;
+  if (b) {
+    std::vector<float> bp(cout_p16, 0.f);
+    std::memcpy(bp.data(), b, d.cout * sizeof(float));
+    JH_CHECK_HIP(hipMalloc(&out->bias, bp.size() * sizeof(float)));
+    JH_CHECK_HIP(hipMemcpy(out->bias, bp.data(), bp.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+
+void free_conv_weights(ConvWeights* w) {
+  if (w->w) (void)hipFree(w->w);
+  if (w->bias) (void)hipFree(w->bias);
+  w->w = w->bias = nullptr;
+}
+
+static int pick_nr(int nb) {
+  int best = 1, best_waste = 1 << 30;
+  for (int nr = 4; nr >= 1; --nr) {
+    const int waste = (nb + nr - 1) / nr * nr - nb;
+    if (waste < best_waste) { best_waste = waste; best = nr; }
+  }
+  return best;
+}
+
+int launch_conv(const ConvDesc& d, const ConvWeights& w, const Act& x, const Act& y,
+                const float* gate, double* stats, hipStream_t s) {
+  JH_REQUIRE(x.Cp == w.cin_p, "conv input channel padding mismatch");
+  JH_REQUIRE(y.Cp == cpad(d.cout), "conv output channel padding mismatch");
+  JH_REQUIRE(x.N == y.N, "batch mismatch");
+  ConvArgs a{};
+  a.x = x.p; a.y = y.p; a.w = w.w; a.bias = w.bias; a.gate = gate; a.stats = stats;
+  a.N = x.N; a.Din = x.D; a.Hin = x.H; a.Win = x.W; a.cin_p = x.Cp;
+  a.Dy = y.D; a.Hy = y.H; a.Wy = y.W; a.cout_p = y.Cp; a.cout_p16 = w.cout_p16;
+  a.ostride = d.ostride; a.nphase = d.nphase; a.phase_stride = w.phase_stride;
+  for (int p = 0; p < d.nphase; ++p) a.phase[p] = d.phase[p];
+  if (d.ostride > 1) { a.Dout = x.D; a.Hout = x.H; a.Wout = x.W; }
+  else conv_out_shape(d, x.D, x.H, x.W, &a.Dout, &a.Hout, &a.Wout);
+  int Do, Ho, Wo;
+  conv_out_shape(d, x.D, x.H, x.W, &Do, &Ho, &Wo);
+  JH_REQUIRE(Do == y.D && Ho == y.H && Wo == y.W, "conv output extent mismatch");
+  const int nr = pick_nr(w.cout_p16 / 16);
+  const size_t budget = 72 * 1024;
+  if (d.nd == 2) {
+    const int small = (a.Wout <= 8) ? 1 : 0;
+    if (d.k == 1 && d.stride == 1) return conv_launch_2d_k1(a, nr, small, budget, s);
+    if (d.k == 2 && d.stride == 1) return conv_launch_2d_k2(a, nr, small, budget, s);
+    if (d.k == 3 && d.stride <= 2) return conv_launch_2d_k3(a, d.stride, nr, small, budget, s);
+    if (d.k == 5 && d.stride <= 2) return conv_launch_2d_k5(a, d.stride, nr, small, budget, s);
+  } else {
+    // small tile when the volume would otherwise give fewer blocks than CUs
+    const long tiles_big = (long)((a.Dout + 1) / 2) * ((a.Hout + 3) / 4) * ((a.Wout + 15) / 16) *
+                           a.N * a.nphase * ((w.cout_p16 / 16 + nr - 1) / nr);
+    const int small = tiles_big < 512 ? 1 : 0;
+    if (d.k == 1 && d.stride == 1) return conv_launch_3d_k1(a, nr, small, budget, s);
+    if (d.k == 2 && d.stride == 2) return conv_launch_3d_k2s2(a, nr, small, budget, s);
+    if (d.k == 3 && d.stride <= 2) return conv_launch_3d_k3(a, d.stride, nr, small, budget, s);
+  }
+  JH_REQUIRE(false, "no convolution kernel for this (nd, k, stride)");
+}
+
+}  // namespace jh

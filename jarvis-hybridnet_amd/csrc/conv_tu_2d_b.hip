@@ -1,0 +1,11 @@
+// 2D kernel family k=3 (stem, fused-MBConv stages).
+#include "conv_mfma.h"
+namespace jh {
+int conv_launch_2d_k3(const ConvArgs& a, int stride, int nr, int small, size_t budget, hipStream_t s) {
+  if (stride == 1)
+    return small ? launch_conv_geom<2, 3, 1, 1, 8, 8>(a, nr, budget, s)
+                 : launch_conv_geom<2, 3, 1, 1, 8, 16>(a, nr, budget, s);
+  return small ? launch_conv_geom<2, 3, 2, 1, 8, 8>(a, nr, budget, s)
+               : launch_conv_geom<2, 3, 2, 1, 8, 16>(a, nr, budget, s);
+}
+}  // namespace jh

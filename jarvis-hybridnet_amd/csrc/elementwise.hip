@@ -1,0 +1,346 @@
+// HBM-bound channel-last kernels around the MFMA convolutions.
+//
+//  norm_apply  InstanceNorm (affine-free, biased variance) + activation +
+//              residual adds, optional pooled sums for squeeze-excite
+//              (efficientnet.py:102-112,115-122; model.py:223-232;
+//               v2vnet.py:17-19,32-43,54-55)
+//  se_gate     squeeze-excite bottleneck MLP -> per-(n,c) sigmoid gate
+//              (efficientnet.py:107-112)
+//  depthwise   k x k depthwise convolution, stride 1 (efficientnet.py:68-71,
+//              model.py:196-203)
+//  fuse        BiFPN fast-normalised fusion node incl. nearest upsample /
+//              2x2 max-pool of the neighbour level (model.py:309-353,119-125)
+//  maxpool2    2x2/2 max pool (model.py:414-419)
+//
+// All of them stream float4 channel vectors; one thread owns a fixed channel
+// quad and walks pixels, so per-channel reductions stay in registers.
+#include "jh_common.h"
+
+namespace jh {
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  if (act == ACT_RELU) return fmaxf(v, 0.f);
+  if (act == ACT_SILU) return v / (1.f + expf(-v));
+  return v;
+}
+
+// Block-level reduction of per-thread float4 partials that belong to channel
+// quad (tid % q), followed by fp64 atomics.  `nvals` = 1 (sum) or 2 (sum, sumsq).
+__device__ __forceinline__ void block_channel_reduce(float4 s1, float4 s2, int nvals, int q,
+                                                     int rows, int tid, bool active,
+                                                     double* dst, int dst_stride, float* sm) {
+  // sm: [rows][q][nvals][4]
+  if (active) {
+    const int c4 = tid % q, r = tid / q;
+    float4* p = reinterpret_cast<float4*>(sm) + ((size_t)r * q + c4) * nvals;
+    p[0] = s1;
+    if (nvals == 2) p[1] = s2;
+  }
+  __syncthreads();
+  for (int i = tid; i < q * 4 * nvals; i += blockDim.x) {
+    const int comp = i & 3, v = (i >> 2) % nvals, c4 = (i >> 2) / nvals;
+    float acc = 0.f;
+    for (int r = 0; r < rows; ++r) acc += sm[(((size_t)r * q + c4) * nvals + v) * 4 + comp];
+    unsafeAtomicAdd(dst + (size_t)(c4 * 4 + comp) * dst_stride + v, (double)acc);
+  }
+}
+
+// ------------------------------------------------------------------ norm_apply
+__global__ __launch_bounds__(256) void norm_apply_kernel(
+    const float* __restrict__ x, const double* __restrict__ stats, float eps, int act,
+    const float* __restrict__ r1, const float* __restrict__ r2, float* __restrict__ y,
+    double* __restrict__ pool, int P, int Cp, int ppb) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int q = Cp >> 2;
+  const int rows = 256 / q;
+  const int tid = threadIdx.x;
+  const bool active = tid < rows * q;
+  const int c4 = tid % q, row = tid / q;
+  const int n = blockIdx.y;
+  float4 mean = make_float4(0, 0, 0, 0), rstd = make_float4(1, 1, 1, 1);
+  if (stats && active) {
+    float m[4], rs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const double* st = stats + ((size_t)n * Cp + c4 * 4 + j) * 2;
+      const double mu = st[0] / (double)P;
+      double var = st[1] / (double)P - mu * mu;
+      if (var < 0.0) var = 0.0;
+      m[j] = (float)mu;
+      rs[j] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    mean = make_float4(m[0], m[1], m[2], m[3]);
+    rstd = make_float4(rs[0], rs[1], rs[2], rs[3]);
+  }
+  const size_t base = (size_t)n * P * Cp;
+  const int p0 = blockIdx.x * ppb;
+  const int p1 = min(P, p0 + ppb);
+  float4 ps = make_float4(0, 0, 0, 0);
+  if (active) {
+    for (int p = p0 + row; p < p1; p += rows) {
+      const size_t off = base + (size_t)p * Cp + c4 * 4;
+      float4 v = *reinterpret_cast<const float4*>(x + off);
+      v.x = (v.x - mean.x) * rstd.x; v.y = (v.y - mean.y) * rstd.y;
+      v.z = (v.z - mean.z) * rstd.z; v.w = (v.w - mean.w) * rstd.w;
+      if (r1) {
+        const float4 a = *reinterpret_cast<const float4*>(r1 + off);
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+      }
+      v.x = act_apply(v.x, act); v.y = act_apply(v.y, act);
+      v.z = act_apply(v.z, act); v.w = act_apply(v.w, act);
+      if (r2) {
+        const float4 a = *reinterpret_cast<const float4*>(r2 + off);
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+      }
+      *reinterpret_cast<float4*>(y + off) = v;
+      ps.x += v.x; ps.y += v.y; ps.z += v.z; ps.w += v.w;
+    }
+  }
+  if (pool)
+    block_channel_reduce(ps, ps, 1, q, rows, tid, active, pool + (size_t)n * Cp, 1, sm);
+}
+
+int launch_norm_apply(const Act& x, const double* stats, float eps, int act, const float* r1,
+                      const float* r2, float* y, double* pool, hipStream_t s) {
+  const int P = (int)x.pixels();
+  const int q = x.Cp / 4;
+  JH_REQUIRE(q >= 1 && q <= 256, "channel count out of range for norm_apply");
+  const int rows = 256 / q;
+  // aim at >= 4 blocks per CU worth of work, 8..64 pixels per row-slot
+  int iters = 8;
+  while ((long)x.N * ((P + rows * iters - 1) / (rows * iters)) > 8192 && iters < 64) iters *= 2;
+  const int ppb = rows * iters;
+  dim3 grid((P + ppb - 1) / ppb, x.N);
+  const size_t sm = pool ? (size_t)rows * q * 4 * sizeof(float) : 0;
+  hipLaunchKernelGGL(norm_apply_kernel, grid, dim3(256), sm, s, x.p, stats, eps, act, r1, r2, y,
+                     pool, P, x.Cp, ppb);
+  JH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// --------------------------------------------------------------------- se_gate
+__global__ __launch_bounds__(256) void se_gate_kernel(
+    const double* __restrict__ pool, int C, int Cp, int S, float inv_hw,
+    const float* __restrict__ wr, const float* __restrict__ br, const float* __restrict__ we,
+    const float* __restrict__ be, float* __restrict__ gate) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [C] means, [S] hidden
+  float* mean = sm;
+  float* hid = sm + C;
+  const int n = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x)
+    mean[c] = (float)(pool[(size_t)n * Cp + c] * (double)inv_hw);
+  __syncthreads();
+  for (int j = threadIdx.x; j < S; j += blockDim.x) {
+    float acc = br[j];
+    for (int c = 0; c < C; ++c) acc = fmaf(wr[j * C + c], mean[c], acc);
+    hid[j] = acc / (1.f + expf(-acc));
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < Cp; c += blockDim.x) {
+    float g = 0.f;
+    if (c < C) {
+      float acc = be[c];
+      for (int j = 0; j < S; ++j) acc = fmaf(we[c * S + j], hid[j], acc);
+      g = 1.f / (1.f + expf(-acc));
+    }
+    gate[(size_t)n * Cp + c] = g;
+  }
+}
+
+int launch_se_gate(const double* pool, int N, int C, int Cp, int S, float inv_hw, const float* wr,
+                   const float* br, const float* we, const float* be, float* gate,
+                   hipStream_t s) {
+  hipLaunchKernelGGL(se_gate_kernel, dim3(N), dim3(256), (C + S) * sizeof(float), s, pool, C, Cp,
+                     S, inv_hw, wr, br, we, be, gate);
+  JH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------- depthwise
+template <int K>
+__global__ __launch_bounds__(256) void depthwise_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
+    double* __restrict__ stats, int H, int W, int Cp, int ppb) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int q = Cp >> 2;
+  const int rows = 256 / q;
+  const int tid = threadIdx.x;
+  const bool active = tid < rows * q;
+  const int c4 = tid % q, row = tid / q;
+  const int n = blockIdx.y;
+  const int P = H * W;
+  const int p0 = blockIdx.x * ppb;
+  const int p1 = min(P, p0 + ppb);
+  const float* xin = x + (size_t)n * P * Cp;
+  float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
+  if (active) {
+    float4 wt[K * K];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t)
+      wt[t] = *reinterpret_cast<const float4*>(w + (size_t)t * Cp + c4 * 4);
+    for (int p = p0 + row; p < p1; p += rows) {
+      const int oy = p / W, ox = p % W;
+      float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+      for (int dy = 0; dy < K; ++dy) {
+        const int iy = oy + dy - K / 2;
+        if (iy < 0 || iy >= H) continue;
+#pragma unroll
+        for (int dx = 0; dx < K; ++dx) {
+          const int ix = ox + dx - K / 2;
+          if (ix < 0 || ix >= W) continue;
+          const float4 v = *reinterpret_cast<const float4*>(xin + ((size_t)iy * W + ix) * Cp + c4 * 4);
+          const float4 k = wt[dy * K + dx];
+          acc.x = fmaf(v.x, k.x, acc.x); acc.y = fmaf(v.y, k.y, acc.y);
+          acc.z = fmaf(v.z, k.z, acc.z); acc.w = fmaf(v.w, k.w, acc.w);
+        }
+      }
+      *reinterpret_cast<float4*>(y + ((size_t)n * P + p) * Cp + c4 * 4) = acc;
+      s1.x += acc.x; s1.y += acc.y; s1.z += acc.z; s1.w += acc.w;
+      s2.x += acc.x * acc.x; s2.y += acc.y * acc.y; s2.z += acc.z * acc.z; s2.w += acc.w * acc.w;
+    }
+  }
+  if (stats)
+    block_channel_reduce(s1, s2, 2, q, rows, tid, active, stats + (size_t)n * Cp * 2, 2, sm);
+}
+
+int launch_depthwise(const Act& x, const float* w, int k, float* y, double* stats, hipStream_t s) {
+  JH_REQUIRE(x.D == 1, "depthwise is 2D only");
+  const int P = x.H * x.W;
+  const int q = x.Cp / 4;
+  JH_REQUIRE(q >= 1 && q <= 256, "channel count out of range for depthwise");
+  const int rows = 256 / q;
+  int iters = 4;
+  while ((long)x.N * ((P + rows * iters - 1) / (rows * iters)) > 8192 && iters < 64) iters *= 2;
+  const int ppb = rows * iters;
+  dim3 grid((P + ppb - 1) / ppb, x.N);
+  const size_t sm = stats ? (size_t)rows * q * 8 * sizeof(float) : 0;
+  if (k == 3)
+    hipLaunchKernelGGL(depthwise_kernel<3>, grid, dim3(256), sm, s, x.p, w, y, stats, x.H, x.W, x.Cp, ppb);
+  else if (k == 5)
+    hipLaunchKernelGGL(depthwise_kernel<5>, grid, dim3(256), sm, s, x.p, w, y, stats, x.H, x.W, x.Cp, ppb);
+  else
+    JH_REQUIRE(false, "depthwise kernel size must be 3 or 5");
+  JH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------ fuse
+__device__ __forceinline__ float4 fuse_fetch(const float* in, int mode, int n, int oy, int ox,
+                                             int H, int W, int Cp, int c) {
+  if (mode == FUSE_SAME)
+    return *reinterpret_cast<const float4*>(in + (((size_t)n * H + oy) * W + ox) * Cp + c);
+  if (mode == FUSE_UP2) {
+    const int h = H >> 1, w = W >> 1;
+    return *reinterpret_cast<const float4*>(in + (((size_t)n * h + (oy >> 1)) * w + (ox >> 1)) * Cp + c);
+  }
+  if (mode == FUSE_UP4) {
+    const int h = H >> 2, w = W >> 2;
+    return *reinterpret_cast<const float4*>(in + (((size_t)n * h + (oy >> 2)) * w + (ox >> 2)) * Cp + c);
+  }
+  // FUSE_POOL2: source is twice the size
+  const int h = H * 2, w = W * 2;
+  const float* b = in + (((size_t)n * h + oy * 2) * w + ox * 2) * Cp + c;
+  const float4 a0 = *reinterpret_cast<const float4*>(b);
+  const float4 a1 = *reinterpret_cast<const float4*>(b + Cp);
+  const float4 a2 = *reinterpret_cast<const float4*>(b + (size_t)w * Cp);
+  const float4 a3 = *reinterpret_cast<const float4*>(b + (size_t)w * Cp + Cp);
+  return make_float4(fmaxf(fmaxf(a0.x, a1.x), fmaxf(a2.x, a3.x)),
+                     fmaxf(fmaxf(a0.y, a1.y), fmaxf(a2.y, a3.y)),
+                     fmaxf(fmaxf(a0.z, a1.z), fmaxf(a2.z, a3.z)),
+                     fmaxf(fmaxf(a0.w, a1.w), fmaxf(a2.w, a3.w)));
+}
+
+__global__ __launch_bounds__(256) void fuse_kernel(FuseArgs f, float* __restrict__ out, int N,
+                                                   int H, int W, int Cp) {
+  const int q = Cp >> 2;
+  const size_t total = (size_t)N * H * W * q;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % q) * 4;
+    size_t p = i / q;
+    const int ox = (int)(p % W); p /= W;
+    const int oy = (int)(p % H);
+    const int n = (int)(p / H);
+    float4 v = fuse_fetch(f.in[0], f.mode[0], n, oy, ox, H, W, Cp, c);
+    // same rounding sequence as the reference expression w0*a + w1*b (+ w2*c)
+    float4 acc = make_float4(__fmul_rn(f.w[0], v.x), __fmul_rn(f.w[0], v.y),
+                             __fmul_rn(f.w[0], v.z), __fmul_rn(f.w[0], v.w));
+    for (int k = 1; k < f.n_in; ++k) {
+      v = fuse_fetch(f.in[k], f.mode[k], n, oy, ox, H, W, Cp, c);
+      acc.x = __fadd_rn(acc.x, __fmul_rn(f.w[k], v.x));
+      acc.y = __fadd_rn(acc.y, __fmul_rn(f.w[k], v.y));
+      acc.z = __fadd_rn(acc.z, __fmul_rn(f.w[k], v.z));
+      acc.w = __fadd_rn(acc.w, __fmul_rn(f.w[k], v.w));
+    }
+    acc.x = act_apply(acc.x, f.act); acc.y = act_apply(acc.y, f.act);
+    acc.z = act_apply(acc.z, f.act); acc.w = act_apply(acc.w, f.act);
+    *reinterpret_cast<float4*>(out + i * 4) = acc;
+  }
+}
+
+int launch_fuse(const FuseArgs& f, const Act& out, hipStream_t s) {
+  const size_t total = (size_t)out.N * out.H * out.W * (out.Cp / 4);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(fuse_kernel, dim3(blocks), dim3(256), 0, s, f, out.p, out.N, out.H, out.W, out.Cp);
+  JH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_maxpool2(const Act& x, float* y, hipStream_t s) {
+  FuseArgs f{};
+  f.in[0] = x.p; f.mode[0] = FUSE_POOL2; f.w[0] = 1.f; f.n_in = 1; f.act = ACT_NONE;
+  Act o = x;
+  o.p = y; o.H = x.H / 2; o.W = x.W / 2;
+  return launch_fuse(f, o, s);
+}
+
+// ---------------------------------------------------------------- layout moves
+__global__ __launch_bounds__(256) void to_channel_last_kernel(const float* __restrict__ src,
+                                                              float* __restrict__ dst, int N, int C,
+                                                              int Cp, size_t P) {
+  const size_t total = (size_t)N * P * Cp;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cp);
+    const size_t p = (i / Cp) % P;
+    const size_t n = i / (Cp * P);
+    dst[i] = (c < C) ? src[(n * C + c) * P + p] : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void from_channel_last_kernel(const float* __restrict__ src,
+                                                                float* __restrict__ dst, int N,
+                                                                int C, int Cp, size_t P) {
+  const size_t total = (size_t)N * C * P;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const size_t p = i % P;
+    const int c = (int)((i / P) % C);
+    const size_t n = i / (P * C);
+    dst[i] = src[(n * P + p) * Cp + c];
+  }
+}
+
+int launch_to_channel_last(const float* src, const Act& dst, hipStream_t s) {
+  const size_t total = dst.elems();
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(to_channel_last_kernel, dim3(blocks), dim3(256), 0, s, src, dst.p, dst.N,
+                     dst.C, dst.Cp, dst.pixels());
+  JH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_from_channel_last(const Act& src, float* dst, hipStream_t s) {
+  const size_t total = (size_t)src.N * src.C * src.pixels();
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(from_channel_last_kernel, dim3(blocks), dim3(256), 0, s, src.p, dst, src.N,
+                     src.C, src.Cp, src.pixels());
+  JH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace jh

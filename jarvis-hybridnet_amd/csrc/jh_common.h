@@ -1,0 +1,142 @@
+// Shared declarations of the MI355X (gfx950) HIP implementation.
+//
+// Activation layout everywhere inside the library: channel-last fp32,
+// [N][D][H][W][Cp] with Cp = channels rounded up to a multiple of 8 and the
+// pad channels held at exactly 0.  2D tensors are D == 1.  This is the layout
+// the MFMA implicit-GEMM convolution wants (K-contiguous operand rows), the
+// layout that makes the reprojection gather a contiguous J-vector per tap,
+// and the layout the V2V input is produced in.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+namespace jh {
+
+constexpr int kWave = 64;
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+inline int cpad(int c) { return round_up(c, 8); }
+
+// thread-local last error text, exported through jh_last_error()
+void set_error(const std::string& msg);
+#define JH_CHECK_HIP(expr)                                                     \
+  do {                                                                         \
+    hipError_t _e = (expr);                                                    \
+    if (_e != hipSuccess) {                                                    \
+      jh::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));        \
+      return 1;                                                                \
+    }                                                                          \
+  } while (0)
+#define JH_REQUIRE(cond, msg)                                                  \
+  do {                                                                         \
+    if (!(cond)) {                                                             \
+      jh::set_error(std::string("requirement failed: ") + #cond + " (" + msg + \
+                    ")");                                                      \
+      return 1;                                                                \
+    }                                                                          \
+  } while (0)
+
+// A channel-last activation tensor in device memory.
+struct Act {
+  float* p = nullptr;
+  int N = 0, D = 1, H = 0, W = 0, C = 0, Cp = 0;
+  size_t pixels() const { return (size_t)D * H * W; }
+  size_t elems() const { return (size_t)N * pixels() * Cp; }
+  size_t bytes() const { return elems() * sizeof(float); }
+};
+
+enum ActKind { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2 };
+
+// ---------------------------------------------------------------- conv (MFMA)
+// One "phase" of a (transposed) convolution: out[o*os + ooff] =
+// sum_t in[o*stride - pad + t] * w[t].  An ordinary conv has one phase with
+// os = 1; ConvTranspose k4 s2 p1 (2D) has 4 phases of 2x2 taps, ConvTranspose
+// k2 s2 (3D) has 8 phases of a single tap.
+struct ConvPhase {
+  int pad[3];    // z, y, x
+  int ooff[3];   // z, y, x
+};
+
+struct ConvDesc {
+  int nd;        // 2 or 3 spatial dims
+  int k;         // taps per dim of each phase
+  int stride;    // input stride
+  int ostride;   // output stride (phases interleave when > 1)
+  int nphase;
+  ConvPhase phase[8];
+  int cin, cout;
+};
+
+// Packed weights of one conv (all phases), see pack_conv_weights().
+struct ConvWeights {
+  float* w = nullptr;      // [phase][tap][cin_p/8][cout_p16/16][64][2]
+  float* bias = nullptr;   // [cout_p16] or nullptr
+  size_t phase_stride = 0; // floats
+  int cin_p = 0, cout_p16 = 0;
+};
+
+struct ConvArgs {
+  const float* x;        // input activation
+  float* y;              // output activation (raw, pre-norm)
+  const float* w;        // packed weights
+  const float* bias;     // [cout_p16] or nullptr
+  const float* gate;     // [N][cin_p] multiplicative gate on the input or nullptr
+  double* stats;         // [N][cout_p][2] (sum, sumsq) accumulated, or nullptr
+  int N, Din, Hin, Win, cin_p;
+  int Dout, Hout, Wout;  // logical conv output extent of ONE phase
+  int Dy, Hy, Wy, cout_p;  // physical output tensor extent
+  int cout_p16;
+  int kc;                // input channels staged per LDS pass (multiple of 8)
+  int ostride, nphase;
+  size_t phase_stride;
+  ConvPhase phase[8];
+};
+
+// host-side repack: torch layout (cout, cin, k..) [transposed: (cin, cout, k..)]
+// -> ConvWeights device buffers.  Returns 0 on success.
+int pack_conv_weights(const ConvDesc& d, const float* w_host, const float* b_host,
+                      bool transposed, ConvWeights* out);
+void free_conv_weights(ConvWeights* w);
+
+int launch_conv(const ConvDesc& d, const ConvWeights& w, const Act& x, const Act& y,
+                const float* gate, double* stats, hipStream_t s);
+// output extent of a conv described by d for an input of extent (D,H,W)
+void conv_out_shape(const ConvDesc& d, int D, int H, int W, int* Do, int* Ho, int* Wo);
+
+ConvDesc conv_desc(int nd, int k, int stride, int pad, int cin, int cout);
+ConvDesc deconv2d_k4s2p1_desc(int cin, int cout);
+ConvDesc deconv3d_k2s2_desc(int cin, int cout);
+
+// ---------------------------------------------------------------- elementwise
+// y = act((x - mean) * rstd + r1) + r2  with per-(n,c) statistics from `stats`
+// (biased variance, eps); optional pooled sum of y per (n,c) into `pool`.
+int launch_norm_apply(const Act& x, const double* stats, float eps, int act,
+                      const float* r1, const float* r2, float* y, double* pool,
+                      hipStream_t s);
+// squeeze-excite gate from pooled sums: gate[n][c] = sigmoid(We silu(Wr mean + br) + be)
+int launch_se_gate(const double* pool, int N, int C, int Cp, int S, float inv_hw,
+                   const float* wr, const float* br, const float* we, const float* be,
+                   float* gate, hipStream_t s);
+// depthwise k x k stride-1 conv, weights [k*k][Cp]; optional IN statistics.
+int launch_depthwise(const Act& x, const float* w, int k, float* y, double* stats,
+                     hipStream_t s);
+// weighted fusion node of the BiFPN: y = act(sum_i w[i] * resample_i(in_i))
+enum FuseMode { FUSE_SAME = 0, FUSE_UP2 = 1, FUSE_UP4 = 2, FUSE_POOL2 = 3 };
+struct FuseArgs {
+  const float* in[3];
+  int mode[3];
+  float w[3];
+  int n_in;
+  int act;
+};
+int launch_fuse(const FuseArgs& f, const Act& out, hipStream_t s);
+int launch_maxpool2(const Act& x, float* y, hipStream_t s);
+
+// ---------------------------------------------------------------- layout moves
+// NCHW/NCDHW fp32 -> channel-last padded (pad channels zeroed) and back.
+int launch_to_channel_last(const float* src, const Act& dst, hipStream_t s);
+int launch_from_channel_last(const Act& src, float* dst, hipStream_t s);
+
+}  // namespace jh

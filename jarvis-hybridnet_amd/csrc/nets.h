@@ -1,0 +1,100 @@
+// Launch plans of the two networks on the hot path.
+//
+// A plan is built once per (weights, input shape): activations are allocated,
+// weights are repacked into MFMA operand order, and the forward pass becomes a
+// flat list of kernel launches on one stream with no host synchronisation and
+// no allocation, so a caller may capture it into a hipGraph.
+#pragma once
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+#include "jh_common.h"
+
+namespace jh {
+
+// kernels implemented in other translation units
+int launch_reproject(const float* cam, const float* intr, const float* dist, const int* center3d,
+                     const int* center_hm, const float* heat, float2* coarse, float* vol,
+                     int* idx_out, int T, int C, int G, float spacing, int hs, int Jp,
+                     int heat_pad, int div255, hipStream_t s);
+int launch_preprocess_resize(const float* frames, float* out, int N, int H, int W, int S,
+                             const float* mean, const float* stdv, hipStream_t s);
+int launch_preprocess_crop(const float* frames, const int* center_hm, float* out, int T, int Cloc,
+                           int C, int cam0, int H, int W, int B, const float* mean,
+                           const float* stdv, hipStream_t s);
+int launch_center_argmax(const float* heat, float* det, int N, int Hh, int Wh, int Cp,
+                         hipStream_t s);
+int launch_triangulate(const float* det, const float* cam, const float* intr, const float* dist,
+                       float* center3d_f, int* center3d_i, int* center_hm, int* valid, int T, int C,
+                       float sx2, float sy2, float wdiv, int hw, int W, int H, hipStream_t s);
+int launch_project_points(const float* pts, const float* cam, const float* intr, const float* dist,
+                          float* uv, int P, int C, hipStream_t s);
+int launch_softargmax(const float* x, const int* center3d, double* partial, int* pmax,
+                      float* points, float* conf, float* heatmap_final, int T, int J, int Jp,
+                      int Gh, float spacing, float roi, hipStream_t s);
+
+typedef std::map<std::string, std::vector<float>> ParamMap;
+
+// Common machinery: owned device buffers, a zero-initialised scratch arena for
+// InstanceNorm statistics / SE pools, and the recorded launch list.
+class Plan {
+ public:
+  ~Plan();
+  int run(hipStream_t s);
+  size_t launches() const { return ops_.size(); }
+  size_t device_bytes() const { return bytes_; }
+
+ protected:
+  int alloc(void** p, size_t bytes);
+  int new_act(int N, int D, int H, int W, int C, Act* out);
+  size_t scratch(size_t doubles);           // offset into the zeroed arena
+  int finish();                             // allocate the arena
+  double* sc(size_t off) const { return arena_ + off; }
+  int upload(const std::vector<float>& host, float** dev);
+  int get(const ParamMap& pm, const std::string& key, size_t numel, const float** out);
+
+  std::vector<std::function<int(hipStream_t)>> ops_;
+  std::vector<void*> owned_;
+  std::vector<ConvWeights> convs_;
+  double* arena_ = nullptr;
+  size_t arena_doubles_ = 0;
+  size_t bytes_ = 0;
+
+  // building blocks shared by both networks
+  int add_conv(const ParamMap& pm, const ConvDesc& d, const std::string& wkey,
+               const std::string& bkey, bool transposed, const Act& x, const Act& y,
+               const float* gate, bool want_stats, size_t* stats_off);
+  void add_norm(const Act& x, size_t stats_off, int act, const float* r1, const float* r2,
+                float* y, long pool_off);
+};
+
+class EffTrackPlan : public Plan {
+ public:
+  // size: 0 small, 1 medium, 2 large.  N images of H x W (multiples of 64).
+  int build(const ParamMap& pm, const std::string& prefix, int size, int J, int N, int H, int W);
+  Act input;     // [N][H][W][8]   normalised image, channel-last
+  Act heat;      // [N][H/2][W/2][Jp]  res2 (ConvTranspose output)
+  int J = 0;
+
+ private:
+  int mbconv(const ParamMap& pm, const std::string& p, int stage, int k, int stride, int cin,
+             int cout, int expand, const Act& x, Act* out);
+  int sepconv(const ParamMap& pm, const std::string& p, int cout, const Act& x, Act* out);
+  int lateral(const ParamMap& pm, const std::string& p, int cout, const Act& x, Act* out);
+  int fuse(int n_in, const Act* ins, const int* modes, const float* w, int act, const Act& like,
+           Act* out);
+};
+
+class V2VPlan : public Plan {
+ public:
+  int build(const ParamMap& pm, const std::string& prefix, int J, int T, int G);
+  Act input;     // [T][G][G][G][Jp]   reprojected volume / 255
+  Act output;    // [T][G/2]^3[Jp]
+
+ private:
+  int res_block(const ParamMap& pm, const std::string& p, int c, const Act& x, const float* extra,
+                Act* out);
+};
+
+}  // namespace jh

@@ -1,0 +1,392 @@
+// Plan builders: EfficientTrack 2D network and V2V 3D network.
+//
+// Architecture restated from the reference (cited per function); the weights
+// are consumed under the reference's own state-dict keys.
+#include <cmath>
+#include <cstring>
+#include "nets.h"
+
+namespace jh {
+
+// ------------------------------------------------------------------------ Plan
+Plan::~Plan() {
+  for (void* p : owned_) (void)hipFree(p);
+  for (auto& c : convs_) free_conv_weights(&c);
+}
+
+int Plan::alloc(void** p, size_t bytes) {
+  JH_CHECK_HIP(hipMalloc(p, bytes));
+  owned_.push_back(*p);
+  bytes_ += bytes;
+  return 0;
+}
+
+int Plan::new_act(int N, int D, int H, int W, int C, Act* out) {
+  out->N = N; out->D = D; out->H = H; out->W = W; out->C = C; out->Cp = cpad(C);
+  if (alloc(reinterpret_cast<void**>(&out->p), out->bytes())) return 1;
+  // pad channels must hold zeros from the start
+  JH_CHECK_HIP(hipMemset(out->p, 0, out->bytes()));
+  return 0;
+}
+
+size_t Plan::scratch(size_t doubles) {
+  const size_t off = arena_doubles_;
+  arena_doubles_ += (doubles + 7) / 8 * 8;
+  return off;
+}
+
+int Plan::finish() {
+  if (arena_doubles_ == 0) arena_doubles_ = 8;
+  return alloc(reinterpret_cast<void**>(&arena_), arena_doubles_ * sizeof(double));
+}
+
+int Plan::run(hipStream_t s) {
+  JH_CHECK_HIP(hipMemsetAsync(arena_, 0, arena_doubles_ * sizeof(double), s));
+  for (auto& op : ops_)
+    if (op(s)) return 1;
+  return 0;
+}
+
+int Plan::upload(const std::vector<float>& host, float** dev) {
+  if (alloc(reinterpret_cast<void**>(dev), host.size() * sizeof(float))) return 1;
+  JH_CHECK_HIP(hipMemcpy(*dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int Plan::get(const ParamMap& pm, const std::string& key, size_t numel, const float** out) {
+  auto it = pm.find(key);
+  JH_REQUIRE(it != pm.end(), "missing parameter " + key);
+  JH_REQUIRE(it->second.size() == numel, "wrong element count for parameter " + key);
+  *out = it->second.data();
+  return 0;
+}
+
+int Plan::add_conv(const ParamMap& pm, const ConvDesc& d, const std::string& wkey,
+                   const std::string& bkey, bool transposed, const Act& x, const Act& y,
+                   const float* gate, bool want_stats, size_t* stats_off) {
+  size_t taps;
+  if (d.ostride > 1) taps = (d.nd == 2) ? 16 : 8;
+  else taps = (size_t)d.k * d.k * (d.nd == 3 ? d.k : 1);
+  const float *w = nullptr, *b = nullptr;
+  if (get(pm, wkey, (size_t)d.cin * d.cout * taps, &w)) return 1;
+  if (!bkey.empty() && get(pm, bkey, d.cout, &b)) return 1;
+  ConvWeights cw;
+  if (pack_conv_weights(d, w, b, transposed, &cw)) return 1;
+  convs_.push_back(cw);
+  bytes_ += cw.phase_stride * d.nphase * sizeof(float);
+  size_t off = 0;
+  if (want_stats) {
+    off = scratch((size_t)y.N * y.Cp * 2);
+    if (stats_off) *stats_off = off;
+  }
+  ops_.push_back([this, d, cw, x, y, gate, want_stats, off](hipStream_t s) {
+    return launch_conv(d, cw, x, y, gate, want_stats ? sc(off) : nullptr, s);
+  });
+  return 0;
+}
+
+void Plan::add_norm(const Act& x, size_t stats_off, int act, const float* r1, const float* r2,
+                    float* y, long pool_off) {
+  ops_.push_back([this, x, stats_off, act, r1, r2, y, pool_off](hipStream_t s) {
+    return launch_norm_apply(x, sc(stats_off), 1e-5f, act, r1, r2, y,
+                             pool_off >= 0 ? sc((size_t)pool_off) : nullptr, s);
+  });
+}
+
+// ---------------------------------------------------------------- EfficientTrack
+namespace {
+struct SizeSpec { double width, depth; int fpn, cells, head; };
+// jarvis/efficienttrack/model.py:34-51, utils.py:152-155
+const SizeSpec kSizes[3] = {{0.5, 0.5, 56, 3, 64}, {1.0, 1.0, 88, 4, 88}, {1.1, 1.2, 160, 6, 160}};
+// jarvis/efficienttrack/utils.py:267-272: kernel, repeats, in, out, expand, stride
+const int kStages[7][6] = {{3, 1, 32, 16, 1, 1}, {3, 2, 16, 24, 6, 2}, {5, 2, 24, 40, 6, 2},
+                           {3, 3, 40, 80, 6, 2}, {5, 3, 80, 112, 6, 1}, {5, 4, 112, 192, 6, 2},
+                           {3, 1, 192, 320, 6, 1}};
+struct Block { int stage, k, stride, cin, cout, expand; };
+
+int scale_ch(int c, double width) {       // utils.py:76-96 (divisor 8)
+  const double f = c * width;
+  int o = std::max(8, (int)(f + 4) / 8 * 8);
+  if (o < 0.9 * f) o += 8;
+  return o;
+}
+
+// trunk after the cut behind the last stride-16 block; taps before the 2nd..4th
+// stride-2 block (efficientnet.py:156-173, model.py:515-533)
+void trunk(int size, int* stem, std::vector<Block>* blocks, int taps[3]) {
+  const SizeSpec& s = kSizes[size];
+  std::vector<Block> all;
+  for (int st = 0; st < 7; ++st) {
+    const int cin = scale_ch(kStages[st][2], s.width), cout = scale_ch(kStages[st][3], s.width);
+    const int rep = (int)std::ceil(s.depth * kStages[st][1]);
+    for (int r = 0; r < rep; ++r)
+      all.push_back({st, kStages[st][0], r == 0 ? kStages[st][5] : 1, r == 0 ? cin : cout, cout,
+                     kStages[st][4]});
+  }
+  int seen = 0, nt = 0;
+  for (size_t i = 0; i < all.size() && nt < 3; ++i)
+    if (all[i].stride == 2 && seen++ >= 1) taps[nt++] = (int)i - 1;
+  blocks->assign(all.begin(), all.begin() + taps[2] + 1);
+  *stem = scale_ch(32, s.width);
+}
+
+// relu(p) / (sum + eps), model.py:309-311 (float arithmetic like the reference)
+void fuse_weights(const float* p, int n, float* w) {
+  float r[3], sum = 0.f;
+  for (int i = 0; i < n; ++i) { r[i] = p[i] > 0.f ? p[i] : 0.f; sum += r[i]; }
+  for (int i = 0; i < n; ++i) w[i] = r[i] / (sum + 1e-4f);
+}
+}  // namespace
+
+// MBConvBlock.forward, efficientnet.py:90-123
+int EffTrackPlan::mbconv(const ParamMap& pm, const std::string& p, int stage, int k, int stride,
+                         int cin, int cout, int expand, const Act& x, Act* out) {
+  const int mid = cin * expand;
+  const int squeeze = std::max(1, (int)(cin * 0.25));
+  const int Ho = (x.H + 2 * (k / 2) - k) / stride + 1, Wo = (x.W + 2 * (k / 2) - k) / stride + 1;
+  Act raw;
+  if (new_act(x.N, 1, Ho, Wo, mid, &raw)) return 1;
+  size_t st1 = 0;
+  if (stage < 4) {
+    // "fused" path: one dense k x k conv; _expand_conv is never executed
+    if (add_conv(pm, conv_desc(2, k, stride, k / 2, cin, mid), p + "_depthwise_conv.weight", "",
+                 false, x, raw, nullptr, true, &st1)) return 1;
+  } else {
+    Act e = x;
+    if (expand != 1) {
+      if (new_act(x.N, 1, x.H, x.W, mid, &e)) return 1;
+      if (add_conv(pm, conv_desc(2, 1, 1, 0, cin, mid), p + "_expand_conv.weight", "", false, x, e,
+                   nullptr, false, nullptr)) return 1;
+    }
+    JH_REQUIRE(stride == 1, "depthwise stages are stride 1");
+    const float* w = nullptr;
+    if (get(pm, p + "_depthwise_conv.weight", (size_t)mid * k * k, &w)) return 1;
+    std::vector<float> wt((size_t)k * k * raw.Cp, 0.f);
+    for (int c = 0; c < mid; ++c)
+      for (int t = 0; t < k * k; ++t) wt[(size_t)t * raw.Cp + c] = w[(size_t)c * k * k + t];
+    float* wd = nullptr;
+    if (upload(wt, &wd)) return 1;
+    st1 = scratch((size_t)raw.N * raw.Cp * 2);
+    ops_.push_back([this, e, wd, k, raw, st1](hipStream_t s) {
+      return launch_depthwise(e, wd, k, raw.p, sc(st1), s);
+    });
+  }
+  // _gn1 + swish, pooled for squeeze-excite (in place)
+  const size_t pool = scratch((size_t)raw.N * raw.Cp);
+  add_norm(raw, st1, ACT_SILU, nullptr, nullptr, raw.p, (long)pool);
+  // squeeze-excite gate
+  const float *wr, *br, *we, *be;
+  if (get(pm, p + "_se_reduce.weight", (size_t)squeeze * mid, &wr)) return 1;
+  if (get(pm, p + "_se_reduce.bias", squeeze, &br)) return 1;
+  if (get(pm, p + "_se_expand.weight", (size_t)mid * squeeze, &we)) return 1;
+  if (get(pm, p + "_se_expand.bias", mid, &be)) return 1;
+  float *dwr, *dbr, *dwe, *dbe, *gate;
+  if (upload(std::vector<float>(wr, wr + (size_t)squeeze * mid), &dwr)) return 1;
+  if (upload(std::vector<float>(br, br + squeeze), &dbr)) return 1;
+  if (upload(std::vector<float>(we, we + (size_t)mid * squeeze), &dwe)) return 1;
+  if (upload(std::vector<float>(be, be + mid), &dbe)) return 1;
+  if (alloc(reinterpret_cast<void**>(&gate), (size_t)raw.N * raw.Cp * sizeof(float))) return 1;
+  const float inv_hw = 1.f / (float)(Ho * Wo);
+  ops_.push_back([this, pool, raw, mid, squeeze, inv_hw, dwr, dbr, dwe, dbe, gate](hipStream_t s) {
+    return launch_se_gate(sc(pool), raw.N, mid, raw.Cp, squeeze, inv_hw, dwr, dbr, dwe, dbe, gate, s);
+  });
+  // project (gate applied while staging the operand) + _gn2 (+ skip)
+  if (new_act(x.N, 1, Ho, Wo, cout, out)) return 1;
+  size_t st2 = 0;
+  if (add_conv(pm, conv_desc(2, 1, 1, 0, mid, cout), p + "_project_conv.weight", "", false, raw,
+               *out, gate, true, &st2)) return 1;
+  const bool skip = (stride == 1 && cin == cout);
+  add_norm(*out, st2, ACT_NONE, skip ? x.p : nullptr, nullptr, out->p, -1);
+  return 0;
+}
+
+// SeparableConvBlock.forward, model.py:223-232 (norm=True, activation=False
+// everywhere it is used on this path, including first_conv)
+int EffTrackPlan::sepconv(const ParamMap& pm, const std::string& p, int cout, const Act& x,
+                          Act* out) {
+  const float* w = nullptr;
+  if (get(pm, p + "depthwise_conv.weight", (size_t)x.C * 9, &w)) return 1;
+  std::vector<float> wt((size_t)9 * x.Cp, 0.f);
+  for (int c = 0; c < x.C; ++c)
+    for (int t = 0; t < 9; ++t) wt[(size_t)t * x.Cp + c] = w[(size_t)c * 9 + t];
+  float* wd = nullptr;
+  if (upload(wt, &wd)) return 1;
+  Act dw;
+  if (new_act(x.N, 1, x.H, x.W, x.C, &dw)) return 1;
+  ops_.push_back([x, wd, dw](hipStream_t s) { return launch_depthwise(x, wd, 3, dw.p, nullptr, s); });
+  if (new_act(x.N, 1, x.H, x.W, cout, out)) return 1;
+  size_t st = 0;
+  if (add_conv(pm, conv_desc(2, 1, 1, 0, x.C, cout), p + "pointwise_conv.weight",
+               p + "pointwise_conv.bias", false, dw, *out, nullptr, true, &st)) return 1;
+  add_norm(*out, st, ACT_NONE, nullptr, nullptr, out->p, -1);
+  return 0;
+}
+
+// 1x1 conv + bias + InstanceNorm (model.py:404-425)
+int EffTrackPlan::lateral(const ParamMap& pm, const std::string& p, int cout, const Act& x,
+                          Act* out) {
+  if (new_act(x.N, 1, x.H, x.W, cout, out)) return 1;
+  size_t st = 0;
+  if (add_conv(pm, conv_desc(2, 1, 1, 0, x.C, cout), p + ".0.weight", p + ".0.bias", false, x,
+               *out, nullptr, true, &st)) return 1;
+  add_norm(*out, st, ACT_NONE, nullptr, nullptr, out->p, -1);
+  return 0;
+}
+
+int EffTrackPlan::fuse(int n_in, const Act* ins, const int* modes, const float* w, int act,
+                       const Act& like, Act* out) {
+  if (new_act(like.N, 1, like.H, like.W, like.C, out)) return 1;
+  FuseArgs f{};
+  f.n_in = n_in; f.act = act;
+  for (int i = 0; i < n_in; ++i) { f.in[i] = ins[i].p; f.mode[i] = modes[i]; f.w[i] = w[i]; }
+  const Act o = *out;
+  ops_.push_back([f, o](hipStream_t s) { return launch_fuse(f, o, s); });
+  return 0;
+}
+
+// EfficientTrackBackbone.forward, model.py:114-130 (res2 branch only: the
+// final_conv1 branch is dead on the inference path, model.py:57-58 / jarvis3D.py:147)
+int EffTrackPlan::build(const ParamMap& pm, const std::string& pre, int size, int joints, int N,
+                        int H, int W) {
+  JH_REQUIRE(size >= 0 && size < 3, "model size");
+  JH_REQUIRE(H % 64 == 0 && W % 64 == 0, "image side must be a multiple of 64");
+  const SizeSpec& ss = kSizes[size];
+  J = joints;
+  int stem, taps[3];
+  std::vector<Block> blocks;
+  trunk(size, &stem, &blocks, taps);
+
+  if (new_act(N, 1, H, W, 3, &input)) return 1;
+  // stem conv + IN + swish (efficientnet.py:150-152, model.py:536-538)
+  Act x;
+  if (new_act(N, 1, H / 2, W / 2, stem, &x)) return 1;
+  size_t st = 0;
+  const std::string bb = pre + "backbone_net.model.";
+  if (add_conv(pm, conv_desc(2, 3, 2, 1, 3, stem), bb + "_conv_stem.weight", "", false, input, x,
+               nullptr, true, &st)) return 1;
+  add_norm(x, st, ACT_SILU, nullptr, nullptr, x.p, -1);
+  Act feats[3];
+  int nf = 0;
+  for (size_t i = 0; i < blocks.size(); ++i) {
+    const Block& b = blocks[i];
+    Act y;
+    if (mbconv(pm, bb + "_blocks." + std::to_string(i) + ".", b.stage, b.k, b.stride, b.cin,
+               b.cout, b.expand, x, &y)) return 1;
+    x = y;
+    if (nf < 3 && (int)i == taps[nf]) feats[nf++] = x;
+  }
+  JH_REQUIRE(nf == 3, "feature taps");
+
+  // BiFPN cells (model.py:301-353, 446-504)
+  const int Wf = ss.fpn;
+  Act p3, p4, p5, p6, p7;
+  for (int cell = 0; cell < ss.cells; ++cell) {
+    const std::string p = pre + "bifpn." + std::to_string(cell) + ".";
+    Act p3_in, p4_in, p5_in, p6_in, p7_in, p4_in2, p5_in2;
+    if (cell == 0) {
+      Act t6;
+      if (lateral(pm, p + "p5_to_p6", Wf, feats[2], &t6)) return 1;
+      if (new_act(N, 1, t6.H / 2, t6.W / 2, Wf, &p6_in)) return 1;
+      { const Act a = t6, o = p6_in; ops_.push_back([a, o](hipStream_t s) { return launch_maxpool2(a, o.p, s); }); }
+      if (new_act(N, 1, p6_in.H / 2, p6_in.W / 2, Wf, &p7_in)) return 1;
+      { const Act a = p6_in, o = p7_in; ops_.push_back([a, o](hipStream_t s) { return launch_maxpool2(a, o.p, s); }); }
+      if (lateral(pm, p + "p3_down_channel", Wf, feats[0], &p3_in)) return 1;
+      if (lateral(pm, p + "p4_down_channel", Wf, feats[1], &p4_in)) return 1;
+      if (lateral(pm, p + "p5_down_channel", Wf, feats[2], &p5_in)) return 1;
+      if (lateral(pm, p + "p4_down_channel_2", Wf, feats[1], &p4_in2)) return 1;
+      if (lateral(pm, p + "p5_down_channel_2", Wf, feats[2], &p5_in2)) return 1;
+    } else {
+      p3_in = p3; p4_in = p4; p5_in = p5; p6_in = p6; p7_in = p7;
+      p4_in2 = p4; p5_in2 = p5;
+    }
+    auto node = [&](const char* wname, int n_in, const Act* ins, const int* modes, const Act& like,
+                    const char* conv, Act* out) -> int {
+      const float* wp = nullptr;
+      if (get(pm, p + wname, n_in, &wp)) return 1;
+      float w[3];
+      fuse_weights(wp, n_in, w);
+      Act f;
+      if (fuse(n_in, ins, modes, w, ACT_SILU, like, &f)) return 1;
+      return sepconv(pm, p + conv + ".", Wf, f, out);
+    };
+    const int m_up[2] = {FUSE_SAME, FUSE_UP2};
+    const int m_dn3[3] = {FUSE_SAME, FUSE_SAME, FUSE_POOL2};
+    const int m_dn2[2] = {FUSE_SAME, FUSE_POOL2};
+    Act p6_up, p5_up, p4_up, p3_out, p4_out, p5_out, p6_out, p7_out;
+    { const Act in[2] = {p6_in, p7_in}; if (node("p6_w1", 2, in, m_up, p6_in, "conv6_up", &p6_up)) return 1; }
+    { const Act in[2] = {p5_in, p6_up}; if (node("p5_w1", 2, in, m_up, p5_in, "conv5_up", &p5_up)) return 1; }
+    { const Act in[2] = {p4_in, p5_up}; if (node("p4_w1", 2, in, m_up, p4_in, "conv4_up", &p4_up)) return 1; }
+    { const Act in[2] = {p3_in, p4_up}; if (node("p3_w1", 2, in, m_up, p3_in, "conv3_up", &p3_out)) return 1; }
+    { const Act in[3] = {p4_in2, p4_up, p3_out}; if (node("p4_w2", 3, in, m_dn3, p4_in2, "conv4_down", &p4_out)) return 1; }
+    { const Act in[3] = {p5_in2, p5_up, p4_out}; if (node("p5_w2", 3, in, m_dn3, p5_in2, "conv5_down", &p5_out)) return 1; }
+    { const Act in[3] = {p6_in, p6_up, p5_out}; if (node("p6_w2", 3, in, m_dn3, p6_in, "conv6_down", &p6_out)) return 1; }
+    { const Act in[2] = {p7_in, p6_out}; if (node("p7_w2", 2, in, m_dn2, p7_in, "conv7_down", &p7_out)) return 1; }
+    p3 = p3_out; p4 = p4_out; p5 = p5_out; p6 = p6_out; p7 = p7_out;
+  }
+
+  // head: softplus-normalised 3-way fusion, first_conv, deconv1 (model.py:119-127)
+  const float* wc = nullptr;
+  if (get(pm, pre + "weights_cat", 3, &wc)) return 1;
+  float w[3], sum = 0.f;
+  for (int i = 0; i < 3; ++i) { w[i] = wc[i] > 20.f ? wc[i] : log1pf(expf(wc[i])); sum += w[i]; }
+  for (int i = 0; i < 3; ++i) w[i] = w[i] / (sum + 0.0001f);
+  const Act hin[3] = {p3, p4, p5};
+  const int hmodes[3] = {FUSE_SAME, FUSE_UP2, FUSE_UP4};
+  Act x1, mid;
+  if (fuse(3, hin, hmodes, w, ACT_NONE, p3, &x1)) return 1;
+  if (sepconv(pm, pre + "first_conv.", ss.head, x1, &mid)) return 1;
+  if (new_act(N, 1, mid.H * 2, mid.W * 2, J, &heat)) return 1;
+  if (add_conv(pm, deconv2d_k4s2p1_desc(ss.head, J), pre + "deconv1.weight", "", true, mid, heat,
+               nullptr, false, nullptr)) return 1;
+  return finish();
+}
+
+// ------------------------------------------------------------------------- V2V
+// Res3DBlock.forward, v2vnet.py:27-43: relu(IN(conv(relu(IN(conv(x))))) + x)
+// `extra`, when set, is added after the final relu (the encoder/decoder skip sum).
+int V2VPlan::res_block(const ParamMap& pm, const std::string& p, int c, const Act& x,
+                       const float* extra, Act* out) {
+  Act a;
+  if (new_act(x.N, x.D, x.H, x.W, c, &a)) return 1;
+  size_t s1 = 0, s2 = 0;
+  if (add_conv(pm, conv_desc(3, 3, 1, 1, c, c), p + "res_branch.0.weight", p + "res_branch.0.bias",
+               false, x, a, nullptr, true, &s1)) return 1;
+  add_norm(a, s1, ACT_RELU, nullptr, nullptr, a.p, -1);
+  if (new_act(x.N, x.D, x.H, x.W, c, out)) return 1;
+  if (add_conv(pm, conv_desc(3, 3, 1, 1, c, c), p + "res_branch.3.weight", p + "res_branch.3.bias",
+               false, a, *out, nullptr, true, &s2)) return 1;
+  add_norm(*out, s2, ACT_RELU, x.p, extra, out->p, -1);
+  return 0;
+}
+
+// V2VNet.forward, v2vnet.py:98-102 with EncoderDecorder.forward :75-83 inlined
+int V2VPlan::build(const ParamMap& pm, const std::string& pre, int J, int T, int G) {
+  JH_REQUIRE(G % 4 == 0, "grid size must be a multiple of 4");
+  const int Gh = G / 2, Gq = G / 4;
+  if (new_act(T, G, G, G, J, &input)) return 1;
+  Act f0, f1, skip, e0, e1, u0, d1;
+  size_t st = 0;
+  if (new_act(T, Gh, Gh, Gh, 2 * J, &f0)) return 1;
+  if (add_conv(pm, conv_desc(3, 3, 2, 1, J, 2 * J), pre + "front_layers.0.block.0.weight",
+               pre + "front_layers.0.block.0.bias", false, input, f0, nullptr, true, &st)) return 1;
+  add_norm(f0, st, ACT_RELU, nullptr, nullptr, f0.p, -1);
+  if (res_block(pm, pre + "front_layers.1.", 2 * J, f0, nullptr, &f1)) return 1;
+  const std::string e = pre + "encoder_decoder.";
+  if (res_block(pm, e + "skip_res1.", 2 * J, f1, nullptr, &skip)) return 1;
+  if (new_act(T, Gq, Gq, Gq, 4 * J, &e0)) return 1;
+  if (add_conv(pm, conv_desc(3, 2, 2, 0, 2 * J, 4 * J), e + "encoder_pool1.block.0.weight",
+               e + "encoder_pool1.block.0.bias", false, f1, e0, nullptr, true, &st)) return 1;
+  add_norm(e0, st, ACT_RELU, nullptr, nullptr, e0.p, -1);
+  if (res_block(pm, e + "mid_res.", 4 * J, e0, nullptr, &e1)) return 1;
+  if (new_act(T, Gh, Gh, Gh, 2 * J, &u0)) return 1;
+  if (add_conv(pm, deconv3d_k2s2_desc(4 * J, 2 * J), e + "decoder_upsample1.block.0.weight",
+               e + "decoder_upsample1.block.0.bias", true, e1, u0, nullptr, true, &st)) return 1;
+  add_norm(u0, st, ACT_RELU, nullptr, nullptr, u0.p, -1);
+  if (res_block(pm, e + "decoder_res1.", 2 * J, u0, skip.p, &d1)) return 1;   // ... + res1
+  if (new_act(T, Gh, Gh, Gh, J, &output)) return 1;
+  if (add_conv(pm, conv_desc(3, 1, 1, 0, 2 * J, J), pre + "output_layer.weight",
+               pre + "output_layer.bias", false, d1, output, nullptr, false, nullptr)) return 1;
+  return finish();
+}
+
+}  // namespace jh

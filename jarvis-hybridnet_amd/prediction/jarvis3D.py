@@ -1,0 +1,76 @@
+"""JarvisPredictor3D on MI355X (mirrors jarvis/prediction/jarvis3D.py:19-190).
+
+Same constructor and forward signature, same attributes (`centerDetect`,
+`hybridNet` with `.effTrack/.reproLayer/.v2vNet`, `reproTool`), same
+`(None, None)` convention when fewer than two cameras see the subject.  The
+reference's acceleration slot (`trt_mode`, jarvis3D.py:42-46) is where this
+implementation lives permanently: `forward` is a single native call that runs
+resize -> CenterDetect -> argmax -> triangulation -> crops -> KeypointDetect ->
+reprojection -> V2V -> soft-argmax without any host synchronisation; the one
+sync happens when the validity flag is read at the API edge.
+"""
+import torch
+import torch.nn as nn
+
+from .. import _native as N
+from .._params import flat_state
+from .._predictor import NativePredictor
+from ..efficienttrack.efficienttrack import EfficientTrack
+from ..hybridnet.hybridnet import HybridNet
+from ..utils.reprojection import ReprojectionTool
+
+
+class JarvisPredictor3D(nn.Module):
+    def __init__(self, cfg, weights_center_detect="latest", weights_hybridnet="latest",
+                 trt_mode="off"):
+        super().__init__()
+        if trt_mode != "off":
+            raise NotImplementedError("TensorRT modes do not exist on MI355X; the native HIP "
+                                      "path is always on")
+        self.cfg = cfg
+        self.centerDetect = EfficientTrack("CenterDetectInference", cfg, weights_center_detect).model
+        self.hybridNet = HybridNet("inference", cfg, weights_hybridnet).model
+        self.bbox_hw = int(cfg.KEYPOINTDETECT.BOUNDING_BOX_SIZE / 2)
+        self.num_cameras = cfg.HYBRIDNET.NUM_CAMERAS
+        self.bounding_box_size = cfg.KEYPOINTDETECT.BOUNDING_BOX_SIZE
+        self.reproTool = ReprojectionTool()
+        self.center_detect_img_size = int(cfg.CENTERDETECT.IMAGE_SIZE)
+        self._native = {}
+
+    def native(self, img_h, img_w, time_batch=1, cam_lo=0, cam_n=None):
+        """The native predictor for a frame size (built on first use)."""
+        key = (img_h, img_w, time_batch, cam_lo, cam_n)
+        pr = self._native.get(key)
+        if pr is None:
+            c = self.cfg
+            pr = NativePredictor(
+                flat_state(self.centerDetect), flat_state(self.hybridNet),
+                num_cameras=self.num_cameras, num_joints=c.KEYPOINTDETECT.NUM_JOINTS,
+                center_size=self.center_detect_img_size, bbox=self.bounding_box_size,
+                roi_cube_size=c.HYBRIDNET.ROI_CUBE_SIZE, grid_spacing=c.HYBRIDNET.GRID_SPACING,
+                img_h=img_h, img_w=img_w, mean=list(c.DATASET.MEAN), std=list(c.DATASET.STD),
+                center_model=c.CENTERDETECT.MODEL_SIZE, kp_model=c.KEYPOINTDETECT.MODEL_SIZE,
+                time_batch=time_batch, cam_lo=cam_lo, cam_n=cam_n)
+            self._native[key] = pr
+        return pr
+
+    def forward(self, imgs, cameraMatrices, intrinsicMatrices, distortionCoefficients):
+        """imgs (C,3,H,W) RGB in [0,1] -> (points3D (1,J,3), confidences (1,J)) or (None, None)."""
+        self.reproTool.cameraMatrices = cameraMatrices
+        self.reproTool.intrinsicMatrices = intrinsicMatrices
+        self.reproTool.distortionCoefficients = distortionCoefficients
+        x = N.dev(imgs)
+        pr = self.native(x.shape[2], x.shape[3])
+        pr.set_calibration(cameraMatrices, intrinsicMatrices, distortionCoefficients)
+        points, conf, valid = pr.forward(x.unsqueeze(0))
+        if int(valid[0].item()) == 0:               # jarvis3D.py:157,187-190
+            return None, None
+        return points, conf
+
+    def forward_batch(self, imgs, cameraMatrices, intrinsicMatrices, distortionCoefficients):
+        """Throughput form: imgs (T,C,3,H,W) independent time steps -> points (T,J,3),
+        confidences (T,J), valid (T) int32; no host synchronisation."""
+        x = N.dev(imgs)
+        pr = self.native(x.shape[3], x.shape[4], time_batch=x.shape[0])
+        pr.set_calibration(cameraMatrices, intrinsicMatrices, distortionCoefficients)
+        return pr.forward(x)

@@ -1,0 +1,130 @@
+"""GPU: single kernels through the C ABI vs the same op in PyTorch-CPU fp32.
+
+Tolerance: these are fp32 kernels with a different summation order than the
+CPU library, so the bar is float32 round-off: max abs error <= 2e-5 x the
+output's max magnitude (x 10 after an InstanceNorm, which divides by sigma).
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.gpu_util import cuda, rel_err, report
+
+pytestmark = pytest.mark.gpu
+
+
+def _conv(nd, kind, k, stride, pad, cin, cout, x, w, b, gate=None, norm_act=-1):
+    from jarvis_hybridnet_amd import _native as N
+    n = x.shape[0]
+    if nd == 2:
+        d, (h, wd) = 1, x.shape[2:]
+    else:
+        d, h, wd = x.shape[2:]
+    xc = cuda(x)
+    if kind == 0:
+        ref_fn = F.conv2d if nd == 2 else F.conv3d
+        ref = ref_fn(x * gate[:, :, None, None] if gate is not None else x, w, b, stride, pad)
+    elif kind == 1:
+        ref = F.conv_transpose2d(x, w, b, 2, 1)
+    else:
+        ref = F.conv_transpose3d(x, w, b, 2, 0)
+    if norm_act >= 0:
+        ref = F.instance_norm(ref, eps=1e-5)
+        ref = [lambda v: v, F.relu, F.silu][norm_act](ref)
+    y = torch.empty(ref.shape, device="cuda")
+    wh, bh = w.contiguous(), (b.contiguous() if b is not None else None)
+    gc = cuda(gate) if gate is not None else None
+    N.check(N.lib().jh_op_conv(nd, kind, k, stride, pad, cin, cout, wh.data_ptr(),
+                               bh.data_ptr() if bh is not None else None, xc.data_ptr(), n, d, h,
+                               wd, N.ptr(gc), norm_act, y.data_ptr(), N.stream()))
+    torch.cuda.synchronize()
+    return y.cpu(), ref
+
+
+CONV2D = [  # k, stride, cin, cout, H, W, bias, norm_act
+    (3, 2, 3, 16, 64, 64, False, 2), (3, 1, 16, 16, 32, 48, False, -1), (3, 2, 8, 48, 40, 40, False, 2),
+    (5, 2, 16, 96, 32, 32, False, -1), (5, 1, 40, 240, 12, 12, False, 2), (1, 1, 240, 56, 16, 16, False, 0),
+    (1, 1, 56, 56, 4, 4, True, 0), (1, 1, 24, 56, 8, 8, True, -1), (3, 1, 40, 240, 16, 16, False, -1),
+    (3, 2, 24, 144, 32, 32, False, 2), (1, 1, 56, 336, 16, 16, False, -1), (1, 1, 336, 56, 6, 10, False, 0),
+]
+
+
+@pytest.mark.parametrize("k,stride,cin,cout,H,W,bias,norm_act", CONV2D)
+def test_conv2d(k, stride, cin, cout, H, W, bias, norm_act):
+    g = torch.Generator().manual_seed(k * 100 + cin)
+    x = torch.randn(2, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    b = torch.randn(cout, generator=g) if bias else None
+    y, ref = _conv(2, 0, k, stride, k // 2, cin, cout, x, w, b, norm_act=norm_act)
+    e = rel_err(y, ref)
+    report("conv2d", k=k, stride=stride, cin=cin, cout=cout, rel=e)
+    assert e < (2e-4 if norm_act >= 0 else 2e-5)
+
+
+def test_conv2d_gate():
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(3, 48, 20, 20, generator=g)
+    w = torch.randn(16, 48, 1, 1, generator=g) / 7
+    gate = torch.rand(3, 48, generator=g)
+    y, ref = _conv(2, 0, 1, 1, 0, 48, 16, x, w, None, gate=gate)
+    e = rel_err(y, ref)
+    report("conv2d_gate", rel=e)
+    assert e < 2e-5
+
+
+def test_deconv2d_k4s2p1():
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 64, 24, 24, generator=g)
+    w = torch.randn(64, 23, 4, 4, generator=g) / 16      # asymmetric: catches tap/phase swaps
+    y, ref = _conv(2, 1, 4, 2, 1, 64, 23, x, w, None)
+    e = rel_err(y, ref)
+    report("deconv2d", rel=e)
+    assert e < 2e-5
+
+
+CONV3D = [  # k, stride, pad, cin, cout, G, norm_act
+    (3, 1, 1, 46, 46, 16, 1), (3, 2, 1, 23, 46, 24, 1), (2, 2, 0, 46, 92, 16, 1), (3, 1, 1, 92, 92, 8, -1),
+    (1, 1, 0, 46, 23, 12, -1), (3, 1, 1, 6, 6, 10, -1),
+]
+
+
+@pytest.mark.parametrize("k,stride,pad,cin,cout,G,norm_act", CONV3D)
+def test_conv3d(k, stride, pad, cin, cout, G, norm_act):
+    g = torch.Generator().manual_seed(k * 10 + cin)
+    x = torch.randn(2, cin, G, G, G, generator=g)
+    w = torch.randn(cout, cin, k, k, k, generator=g) / (cin * k ** 3) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    y, ref = _conv(3, 0, k, stride, pad, cin, cout, x, w, b, norm_act=norm_act)
+    e = rel_err(y, ref)
+    report("conv3d", k=k, stride=stride, cin=cin, cout=cout, rel=e)
+    assert e < (2e-4 if norm_act >= 0 else 2e-5)
+
+
+def test_deconv3d_k2s2():
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 92, 8, 8, 8, generator=g)
+    w = torch.randn(92, 46, 2, 2, 2, generator=g) / 10
+    b = torch.randn(46, generator=g) * 0.1
+    y, ref = _conv(3, 2, 2, 2, 0, 92, 46, x, w, b, norm_act=1)
+    e = rel_err(y, ref)
+    report("deconv3d", rel=e)
+    assert e < 2e-4
+
+
+@pytest.mark.parametrize("k,c,H,W,norm_act", [(3, 56, 32, 32, -1), (5, 240, 16, 16, 2), (3, 88, 8, 8, -1),
+                                              (5, 336, 12, 20, 2)])
+def test_depthwise(k, c, H, W, norm_act):
+    from jarvis_hybridnet_amd import _native as N
+    g = torch.Generator().manual_seed(k + c)
+    x = torch.randn(2, c, H, W, generator=g)
+    w = torch.randn(c, 1, k, k, generator=g) / k
+    ref = F.conv2d(x, w, None, 1, k // 2, 1, c)
+    if norm_act >= 0:
+        ref = F.silu(F.instance_norm(ref, eps=1e-5))
+    xc, y = cuda(x), torch.empty(ref.shape, device="cuda")
+    N.check(N.lib().jh_op_depthwise(k, c, w.contiguous().data_ptr(), xc.data_ptr(), 2, H, W,
+                                    norm_act, y.data_ptr(), N.stream()))
+    torch.cuda.synchronize()
+    e = rel_err(y, ref)
+    report("depthwise", k=k, c=c, rel=e)
+    assert e < 2e-5 * (10 if norm_act >= 0 else 1)

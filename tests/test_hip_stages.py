@@ -1,0 +1,129 @@
+"""GPU: each stage of the hot path (HIP, through the reference-shaped Python
+API) against the CPU oracle on the seeded cases of tests/cases.py.
+
+Floating-point bars (fp32 kernels, different summation order than the CPU
+libraries): network outputs <= 1e-3 x max magnitude, 3D coordinates <= 1e-3 mm
+(north-star tolerance).  Integer paths (gather indices, argmax, truncated
+centres) must be bit-exact.
+"""
+import pytest
+import torch
+
+from tests import cases
+from tests.gpu_util import cuda, max_err, rel_err, report
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("tag", ["cfg1_small_j12", "small_j1_b2", "small_j23_b2", "small_j23_128",
+                                 "medium_j23", "large_j23"])
+def test_efficienttrack(tag):
+    from jarvis_hybridnet_amd import synthetic as S
+    from jarvis_hybridnet_amd.efficienttrack.model import EfficientTrackBackbone
+    from oracle import hybridnet_oracle as O
+    size, J, N, hw, wseed, xseed = cases.EFFTRACK_CASES[tag]
+    sd = S.efficienttrack_weights(size, J, wseed)
+    x = cases.efftrack_input(N, hw, xseed)
+    with torch.no_grad():
+        ref = O.efficienttrack_forward(sd, x, size, want_res1=False)[1]
+    net = EfficientTrackBackbone(None, size, J)
+    net.load_state_dict(sd, strict=True)
+    res1, res2 = net(cuda(x))
+    torch.cuda.synchronize()
+    assert res1 is None
+    e = rel_err(res2, ref)
+    report("efficienttrack", tag=tag, rel=e, absmax=float(ref.abs().max()))
+    assert e < 1e-3
+    # argmax of every heatmap channel agrees (integer path of the 2D detector)
+    a = res2.cpu().flatten(2).argmax(2)
+    b = ref.flatten(2).argmax(2)
+    top2 = ref.flatten(2).topk(2, dim=2)[0]
+    safe = (top2[..., 0] - top2[..., 1]) > 1e-3 * top2[..., 0].abs()
+    assert torch.equal(a[safe], b[safe])
+
+
+@pytest.mark.parametrize("tag", ["j3_g16", "j23_g48", "j23_g64"])
+def test_v2v_and_tail(tag, golden):
+    from jarvis_hybridnet_amd import _native as N
+    from jarvis_hybridnet_amd import synthetic as S
+    from jarvis_hybridnet_amd.hybridnet.v2vnet import V2VNet
+    from oracle import hybridnet_oracle as O
+    J, G, wseed, xseed = cases.V2V_CASES[tag]
+    sd = S.v2v_weights(J, wseed)
+    x = cases.v2v_input(J, G, xseed)
+    center = torch.tensor([[35, -58, 549]], dtype=torch.int32)
+    with torch.no_grad():
+        ref = O.v2v_forward(sd, x)
+        rfin, rpts, rconf = O.softargmax_tail(ref, center, G * 2, 2)
+    net = V2VNet(J, J)
+    net.load_state_dict(sd, strict=True)
+    out = net(cuda(x))
+    torch.cuda.synchronize()
+    e = rel_err(out, ref)
+    # tail on the HIP output
+    Gh = G // 2
+    fin = torch.empty((1, J, Gh, Gh, Gh), device="cuda")
+    pts = torch.empty((1, J, 3), device="cuda")
+    conf = torch.empty((1, J), device="cuda")
+    N.check(N.lib().jh_softargmax(out.data_ptr(), 1, J, Gh, 2.0, float(G * 2), cuda(center).data_ptr(),
+                                  fin.data_ptr(), pts.data_ptr(), conf.data_ptr(), N.stream()))
+    torch.cuda.synchronize()
+    ep, ec, ef = max_err(pts, rpts), max_err(conf, rconf), rel_err(fin, rfin)
+    report("v2v", tag=tag, rel=e, points_mm=ep, conf=ec, final_rel=ef)
+    assert e < 1e-3
+    assert ep < 1e-3, "3D coordinates must match within 1e-3 mm"
+    assert ec < 1e-5 and ef < 1e-4
+    # and against the reference's own golden numbers
+    g = golden("v2v")
+    assert (pts.cpu() - torch.from_numpy(g[tag + ".points"])).abs().max() < 1e-3
+
+
+@pytest.mark.parametrize("tag", ["tiny", "cfg2", "cfg3", "cfg5"])
+def test_reprojection(tag, golden):
+    from types import SimpleNamespace as NS
+    from jarvis_hybridnet_amd.hybridnet.repro_layer import ReprojectionLayer
+    from oracle import hybridnet_oracle as O
+    C, J, G, spacing, bbox, W, H, focal, seed = cases.REPRO_CASES[tag]
+    inp = cases.repro_inputs(tag)
+    cfg = NS(HYBRIDNET=NS(GRID_SPACING=spacing, ROI_CUBE_SIZE=G * spacing, NUM_CAMERAS=C),
+             KEYPOINTDETECT=NS(BOUNDING_BOX_SIZE=bbox))
+    layer = ReprojectionLayer(cfg)
+    args = [cuda(inp[k]) for k in ("hm_pad", "center3d", "center_hm", "cam", "intr", "dist")]
+    vol = layer(*args)
+    idx = layer.gather_indices(*args)
+    torch.cuda.synchronize()
+    if tag == "cfg5":       # oracle too slow/large for the test budget: golden samples only
+        from tests.util import check_summary
+        g = golden("reprojection")
+        check_summary(g, tag + ".idx", idx.cpu())
+        check_summary(g, tag + ".vol", vol.cpu(), rtol=1e-5, atol=1e-4)
+        return
+    rvol, ridx = O.reprojection_forward(inp["hm_pad"], inp["center3d"], inp["center_hm"],
+                                        inp["cam"], inp["intr"], inp["dist"], G * spacing, spacing,
+                                        chunk=5, return_idx=True)
+    mism = int((idx.cpu() != ridx).sum())
+    e = max_err(vol, rvol)
+    report("reprojection", tag=tag, idx_mismatch=mism, n_idx=ridx.numel(), vol_abs=e)
+    assert mism == 0, "gather indices are an integer path: must be bit-exact"
+    assert e < 1e-4 * float(rvol.abs().max())
+
+
+@pytest.mark.parametrize("tag", ["c4", "c12"])
+def test_geometry(tag, golden):
+    from jarvis_hybridnet_amd import synthetic as S
+    from jarvis_hybridnet_amd.utils.reprojection import ReprojectionTool
+    C, W, H, focal, seed = cases.GEOM_CASES[tag]
+    cam, intr, dist = S.ring_calibration(C, W, H, focal)
+    pts2d, maxvals, p3d = cases.geom_inputs(tag)
+    tool = ReprojectionTool()
+    tool.cameraMatrices, tool.intrinsicMatrices = cuda(cam), cuda(intr)
+    tool.distortionCoefficients = cuda(dist)
+    rec = tool.reconstructPoint(cuda(pts2d), cuda(maxvals))
+    rep = tool.reprojectPoint(cuda(p3d))
+    torch.cuda.synchronize()
+    g = golden("geometry")
+    e_rec = (rec.cpu() - torch.from_numpy(g[tag + ".reconstruct"])).abs().max().item()
+    e_rep = (rep.cpu() - torch.from_numpy(g[tag + ".reproject"])).abs().max().item()
+    report("geometry", tag=tag, reconstruct_mm=e_rec, reproject_px=e_rep)
+    assert e_rec < 1e-3          # fp64 eigen-solve vs the reference's fp32 SVD
+    assert e_rep < 1e-3
