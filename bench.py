@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Benchmark of the multi-view inference hot path on MI355X.
+
+Metric (BASELINE.json): multi-view frames/s.  One "step" = one pass of the hot
+path (JarvisPredictor3D.forward: resize -> CenterDetect -> argmax ->
+triangulation -> crops -> KeypointDetect -> reprojection -> V2V -> soft-argmax)
+over one time batch of T independent synthetic multi-view frames that are
+already resident in HBM as fp32 (C,3,H,W) tensors (the API's input type).
+Workload = BASELINE.json configs[2]: 12 cameras 1280x1024, 23 keypoints, 64^3
+voxel grid, small/small models, fp32 (the reference's precision).
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL); cameras are
+sharded over the ranks (jarvis_hybridnet_amd/distributed.py).  Rank 0 prints ONE
+JSON line; `roofline` is measured live with HIP events around every launch of a
+profiled pass, `cpu_baseline` times the CPU oracle on the host cores (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+CONFIGS = {
+    "cfg3": dict(C=12, W=1280, H=1024, J=23, roi=128, spacing=2, bbox=256, center=256, focal=1800.0),
+    "cfg2": dict(C=4, W=640, H=512, J=23, roi=96, spacing=2, bbox=256, center=256, focal=900.0),
+}
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def usable_cores():
+    """Host cores this process may really use: affinity mask capped by the cgroup
+    CPU quota (the GPU boxes expose 256 logical CPUs but a 16-CPU quota)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--time-batch", type=int, default=8, help="multi-view frames per step")
+    ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
+    ap.add_argument("--exchange", default="alltoall", choices=["alltoall", "allgather"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" %
+                         (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from jarvis_hybridnet_amd import _native as N
+    from jarvis_hybridnet_amd import synthetic as S
+    from jarvis_hybridnet_amd._predictor import NativePredictor
+
+    c = CONFIGS[args.config]
+    # Weak scaling: every rank always does the work of `--time-batch` whole frames
+    # (T*C images of 2D work, T frames of 3D work).  Ranks form groups of `gs` GPUs
+    # that shard the cameras of T*gs frames; world/gs groups run side by side.
+    gs = max(d for d in range(1, world + 1) if world % d == 0 and c["C"] % d == 0)
+    n_groups = world // gs
+    grank, gidx = rank % gs, rank // gs
+    T = args.time_batch * gs                       # frames per group and step
+    calib = S.ring_calibration(c["C"], c["W"], c["H"], c["focal"])
+    sd_c = S.efficienttrack_weights("small", 1, 50)
+    sd_h = S.hybridnet_weights("small", c["J"], 51)
+    distinct = [S.blob_frames(calib, c["W"], c["H"], c["J"], 52 + i)[0] for i in range(min(T, 2))]
+    frames = torch.stack([distinct[t % len(distinct)] for t in range(T)])      # (T,C,3,H,W)
+
+    common = dict(num_cameras=c["C"], num_joints=c["J"], center_size=c["center"], bbox=c["bbox"],
+                  roi_cube_size=c["roi"], grid_spacing=c["spacing"], img_h=c["H"], img_w=c["W"],
+                  mean=S.MEAN, std=S.STD, time_batch=T)
+    if world == 1:
+        pred = NativePredictor(sd_c, sd_h, **common)
+        pred.set_calibration(*[t.to(dev) for t in calib])
+        fr = frames.to(dev).contiguous()
+        out = (torch.empty((T, c["J"], 3), device=dev), torch.empty((T, c["J"]), device=dev),
+               torch.empty((T,), device=dev, dtype=torch.int32))
+
+        def step():
+            return pred.forward(fr, out)
+    else:
+        from jarvis_hybridnet_amd.distributed import ShardedPredictor, camera_range
+        groups = [dist.new_group(list(range(g * gs, (g + 1) * gs))) for g in range(n_groups)]
+        cam_lo, cam_n = camera_range(c["C"], grank, gs)
+        pred = NativePredictor(sd_c, sd_h, time_batch_3d=T // gs, cam_lo=cam_lo, cam_n=cam_n,
+                               **common)
+        pred.set_calibration(*[t.to(dev) for t in calib])
+        fr = frames[:, cam_lo:cam_lo + cam_n].to(dev).contiguous()
+        sh = ShardedPredictor(pred, num_cameras=c["C"], num_joints=c["J"], time_batch=T,
+                              heat_shape=(pred.Hh, pred.Hh, pred.Jp), rank=grank, world=gs,
+                              device=dev, exchange=args.exchange, group=groups[gidx])
+
+        def step():
+            return sh.step(fr)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(1, args.warmup)):
+        res = step()
+    run = step
+    if args.graph and world == 1:
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            step()
+        run = g.replay
+        run()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    res = step()
+    torch.cuda.synchronize()
+    valid = int(res[2].sum().item())
+    fps = T * n_groups * args.steps / dt
+
+    line = {
+        "metric": "multi-view frames/s (12cam 1280x1024, 23kpt, 64^3 grid)",
+        "value": fps, "unit": "multi-view frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic (seeded blob frames, ring calibration, random-init weights)",
+        "config": {"workload": "BASELINE configs[2]: HybridNet 12-camera 1280x1024, 23 kpts, "
+                               "64^3 grid, small/small" if args.config == "cfg3" else args.config,
+                   "cameras": c["C"], "frame": [c["H"], c["W"]], "joints": c["J"],
+                   "grid": int(c["roi"] / c["spacing"]), "time_batch": T,
+                   "frames_per_step": T * n_groups, "valid_frames_last_step": valid,
+                   "parallelism": "single GPU" if world == 1 else
+                   "%d group(s) x %d GPUs: camera-sharded 2D (%d cams/GPU) + RCCL %s of "
+                   "heatmaps + frame-sharded 3D" % (n_groups, gs, c["C"] // gs, args.exchange),
+                   "launches_per_step": int(pred.launches), "hipgraph": bool(args.graph)},
+    }
+
+    if rank == 0 and world == 1:
+        # ---- roofline of the dominant kernel, HIP events around every launch
+        recs = []
+        for _ in range(3):
+            recs += N.profile(step)
+        agg = {}
+        for name, ms, fl, by in recs:
+            a = agg.setdefault(name, [0.0, 0, fl, by])
+            a[0] += ms
+            a[1] += 1
+        total_ms = sum(a[0] for a in agg.values())
+        top = sorted(agg.items(), key=lambda kv: -kv[1][0])
+        name, (ms, cnt, fl, by) = top[0]
+        avg_s = ms / cnt * 1e-3
+        if fl > 0 and name.startswith("conv"):
+            line["roofline"] = {"kernel": name, "bound": "mfma", "achieved": fl / avg_s / 1e12,
+                                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                "frac": fl / avg_s / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                                "avg_launch_ms": ms / cnt, "launches_per_step": cnt // 3,
+                                "share_of_step": ms / total_ms}
+        else:
+            line["roofline"] = {"kernel": name, "bound": "hbm", "achieved": by / avg_s / 1e9,
+                                "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                "frac": by / avg_s / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                                "avg_launch_ms": ms / cnt, "launches_per_step": cnt // 3,
+                                "share_of_step": ms / total_ms}
+        line["kernel_breakdown_ms_per_step"] = {k: round(v[0] / 3, 4) for k, v in top[:12]}
+        line["kernel_time_ms_per_step"] = total_ms / 3
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # ---- CPU baseline: the oracle (port of the reference) on the host cores,
+        # same workload, bounded sample of whole frames
+        from oracle import hybridnet_oracle as O
+        cores = usable_cores()
+        torch.set_num_threads(cores)
+        kw = dict(center_size=c["center"], bbox=c["bbox"], roi_cube_size=c["roi"],
+                  grid_spacing=c["spacing"], mean=S.MEAN, std=S.STD)
+        with torch.no_grad():
+            ref = O.predictor3d_forward(sd_c, sd_h, frames[0], *calib, **kw)     # warm-up
+            n, t0 = 0, time.perf_counter()
+            while n < 1 or (time.perf_counter() - t0 < args.cpu_seconds and n < 50):
+                O.predictor3d_forward(sd_c, sd_h, frames[n % len(distinct)], *calib, **kw)
+                n += 1
+            cpu_dt = time.perf_counter() - t0
+        line["cpu_baseline"] = {"value": n / cpu_dt, "unit": "multi-view frames/s", "cores": cores,
+                                "kind": "port",
+                                "sample": "%d whole frames of the same workload through the CPU "
+                                          "oracle (torch %s, %d threads)" % (n, torch.__version__, cores)}
+        if ref[0] is not None:
+            # NOTE: torch's CPU kernels differ in the last bit between CPU models, which
+            # flips a few reprojection gather indices of the reference itself (DESIGN.md,
+            # "reproducibility of the reference"); the pinned comparison is the next one.
+            line["parity_max_abs_mm_vs_host_oracle"] = (res[0][0].cpu() - ref[0][0]).abs().max().item()
+    if rank == 0 and world == 1 and args.config == "cfg3":
+        # frame 0 of this workload is fixture case `cfg3` of tests/golden/predictor.npz,
+        # i.e. the output of the imported upstream reference on the same input
+        import numpy as np
+        gpath = os.path.join(ROOT, "tests", "golden", "predictor.npz")
+        if os.path.isfile(gpath):
+            gold = np.load(gpath)["cfg3.points3D"]
+            line["parity_max_abs_mm_vs_reference_fixture"] = float(
+                np.abs(res[0][0].cpu().numpy() - gold[0]).max())
+
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -101,7 +101,8 @@ typedef struct {
   float grid_spacing;         /* HYBRIDNET.GRID_SPACING (mm) */
   int32_t center_model, kp_model;   /* 0 small, 1 medium, 2 large */
   int32_t img_h, img_w;
-  int32_t time_batch;
+  int32_t time_batch;         /* T: frames per call through the 2D stages */
+  int32_t time_batch_3d;      /* frames per stage_3d call (<= T; 0 means T) */
   int32_t cam_lo, cam_n;
   float mean[3], std[3];      /* DATASET.MEAN / DATASET.STD */
 } jh_predictor_config;
@@ -128,10 +129,11 @@ int jh_predictor_stage_center(jh_predictor* pr, const float* frames_dev, float* 
  * to 8. */
 int jh_predictor_stage_keypoints(jh_predictor* pr, const float* frames_dev,
                                  const float* det_all_dev, float* heat_dev, void* stream);
-/* Stage 3 (model.py:65-88): heat_all (T,C,B/2,B/2,Jp) of ALL cameras -> points
- * (T,J,3), conf (T,J), valid (T) int32 (0 = fewer than two cameras saw the
+/* Stage 3 (model.py:65-88) for the time_batch_3d frames t0 .. t0+T3-1 of the
+ * batch: heat_all (T3,C,B/2,B/2,Jp) of ALL cameras for those frames -> points
+ * (T3,J,3), conf (T3,J), valid (T3) int32 (0 = fewer than two cameras saw the
  * subject: the reference returns (None, None), jarvis3D.py:187-190). */
-int jh_predictor_stage_3d(jh_predictor* pr, const float* heat_all_dev, float* points_dev,
+int jh_predictor_stage_3d(jh_predictor* pr, const float* heat_all_dev, int t0, float* points_dev,
                           float* conf_dev, int32_t* valid_dev, void* stream);
 /* All three stages for cam_lo = 0, cam_n = num_cameras. */
 int jh_predictor_forward(jh_predictor* pr, const float* frames_dev, float* points_dev,
@@ -148,6 +150,14 @@ int jh_predictor_hybridnet_forward(jh_predictor* pr, const float* crops_dev,
                                    const int32_t* center_hm_dev, const int32_t* center3d_dev,
                                    float* heatmap_final_dev, float* heatmaps_padded_dev,
                                    float* points_dev, float* conf_dev, void* stream);
+
+/* ---- per-launch timing (HIP events on the launch stream; used by bench.py for
+ * the roofline figures).  begin() switches recording on for every kernel the
+ * library launches from this process; end() synchronises and returns the number
+ * of records; get() returns name, milliseconds, algorithmic FLOPs and bytes. */
+int jh_profile_begin(void);
+int jh_profile_end(int* n_records);
+int jh_profile_get(int i, char* name, int name_cap, double* ms, double* flops, double* bytes);
 
 /* ---- single-operator entry points (building blocks; used by the unit tests)
  * conv: x (N,Cin,[D,]H,W) -> y; weights/bias are HOST pointers in torch layout

@@ -23,7 +23,8 @@ class PredictorConfig(ctypes.Structure):
                 ("roi_cube_size", c_float), ("grid_spacing", c_float),
                 ("center_model", ctypes.c_int32), ("kp_model", ctypes.c_int32),
                 ("img_h", ctypes.c_int32), ("img_w", ctypes.c_int32),
-                ("time_batch", ctypes.c_int32), ("cam_lo", ctypes.c_int32),
+                ("time_batch", ctypes.c_int32), ("time_batch_3d", ctypes.c_int32),
+                ("cam_lo", ctypes.c_int32),
                 ("cam_n", ctypes.c_int32), ("mean", c_float * 3), ("std", c_float * 3)]
 
 
@@ -58,7 +59,12 @@ _SIGS = {
     "jh_predictor_set_calibration": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "jh_predictor_stage_center": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "jh_predictor_stage_keypoints": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "jh_predictor_stage_3d": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "jh_predictor_stage_3d": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                      c_void_p]),
+    "jh_profile_begin": (c_int, []),
+    "jh_profile_end": (c_int, [ctypes.POINTER(c_int)]),
+    "jh_profile_get": (c_int, [c_int, c_char_p, c_int, ctypes.POINTER(ctypes.c_double),
+                               ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "jh_predictor_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "jh_predictor_debug": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "jh_predictor_hybridnet_forward": (c_int, [c_void_p] * 9),
@@ -133,3 +139,21 @@ class Params:
         if getattr(self, "handle", None) and _lib is not None:
             _lib.jh_params_destroy(self.handle)
             self.handle = None
+
+
+def profile(fn):
+    """Run fn() with per-launch HIP-event timing; returns a list of
+    (kernel name, milliseconds, algorithmic flops, algorithmic bytes)."""
+    check(lib().jh_profile_begin())
+    try:
+        fn()
+    finally:
+        n = c_int(0)
+        check(lib().jh_profile_end(ctypes.byref(n)))
+    out = []
+    buf = ctypes.create_string_buffer(128)
+    ms, fl, by = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    for i in range(n.value):
+        check(lib().jh_profile_get(i, buf, 128, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)))
+        out.append((buf.value.decode(), ms.value, fl.value, by.value))
+    return out

@@ -13,14 +13,15 @@ class NativePredictor:
 
     def __init__(self, center_state, hybrid_state, *, num_cameras, num_joints, center_size, bbox,
                  roi_cube_size, grid_spacing, img_h, img_w, mean, std, center_model="small",
-                 kp_model="small", time_batch=1, cam_lo=0, cam_n=None):
+                 kp_model="small", time_batch=1, time_batch_3d=0, cam_lo=0, cam_n=None):
         cam_n = num_cameras if cam_n is None else cam_n
         cfg = N.PredictorConfig(
             num_cameras, num_joints, center_size, bbox, float(roi_cube_size), float(grid_spacing),
-            arch.SIZE_IDS[center_model], arch.SIZE_IDS[kp_model], img_h, img_w, time_batch, cam_lo,
-            cam_n, (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std))
+            arch.SIZE_IDS[center_model], arch.SIZE_IDS[kp_model], img_h, img_w, time_batch,
+            time_batch_3d, cam_lo, cam_n, (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std))
         self.cfg = cfg
         self.T, self.C, self.Cloc, self.J = time_batch, num_cameras, cam_n, num_joints
+        self.T3 = time_batch_3d if time_batch_3d > 0 else time_batch
         self.Jp = (num_joints + 7) // 8 * 8
         self.Hh = bbox // 2
         self.handle = ctypes.c_void_p()
@@ -63,8 +64,8 @@ class NativePredictor:
         N.check(N.lib().jh_predictor_stage_keypoints(self.handle, N.ptr(frames), N.ptr(det_all),
                                                      N.ptr(heat), N.stream()))
 
-    def stage_3d(self, heat_all, points, conf, valid):
-        N.check(N.lib().jh_predictor_stage_3d(self.handle, N.ptr(heat_all), N.ptr(points),
+    def stage_3d(self, heat_all, t0, points, conf, valid):
+        N.check(N.lib().jh_predictor_stage_3d(self.handle, N.ptr(heat_all), t0, N.ptr(points),
                                               N.ptr(conf), N.ptr(valid), N.stream()))
 
     def debug(self, device):

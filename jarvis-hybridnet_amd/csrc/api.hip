@@ -178,8 +178,18 @@ int jh_reconstruct_point(const float* points2d_dev, const float* maxvals_dev, in
 }  // extern "C"
 
 // ------------------------------------------------------------------- predictor
+// time one glue launch when the profiler is on
+#define JH_PROF(name, flops, bytes, call)                      \
+  do {                                                         \
+    Profiler& _pf = profiler();                                \
+    if (_pf.on) _pf.begin(name, flops, bytes, s);              \
+    if (call) return 1;                                        \
+    if (_pf.on) _pf.end(s);                                    \
+  } while (0)
+
 struct jh_predictor {
   jh_predictor_config cfg{};
+  int T3 = 0;
   int T = 0, C = 0, Cloc = 0, J = 0, Jp = 0, B = 0, Hh = 0, G = 0, Gh = 0, hs = 0;
   std::unique_ptr<EffTrackPlan> center, kp;
   std::unique_ptr<V2VPlan> v2v;
@@ -191,13 +201,20 @@ struct jh_predictor {
   double* sa_partial = nullptr;
   int* sa_max = nullptr;
 
-  int run_3d(const float* heat_all, float* heatmap_final, float* points, float* conf,
+  // 3D stage for frames t0 .. t0+T3-1 of the batch (heat_all holds those frames)
+  int run_3d(const float* heat_all, int t0, float* heatmap_final, float* points, float* conf,
              hipStream_t s) {
-    if (launch_reproject(cam, intr, dist, c3i, chm, heat_all, coarse, v2v->input.p, nullptr, T, C,
-                         G, cfg.grid_spacing, hs, Jp, /*heat_pad=*/0, /*div255=*/1, s)) return 1;
+    const double g3 = (double)G * G * G;
+    // algorithmic traffic of the gather: every heatmap byte once in, the volume once out
+    JH_PROF("reproject_gather", 0.0, 4.0 * T3 * ((double)C * Hh * Hh * J + g3 * J),
+            launch_reproject(cam, intr, dist, c3i + t0 * 3, chm + t0 * C * 2, heat_all, coarse,
+                             v2v->input.p, nullptr, T3, C, G, cfg.grid_spacing, hs, Jp,
+                             /*heat_pad=*/0, /*div255=*/1, s));
     if (v2v->run(s)) return 1;
-    return launch_softargmax(v2v->output.p, c3i, sa_partial, sa_max, points, conf, heatmap_final, T,
-                             J, Jp, Gh, cfg.grid_spacing, cfg.roi_cube_size, s);
+    JH_PROF("softargmax", 0.0, 4.0 * T3 * (g3 / 8) * J,
+            launch_softargmax(v2v->output.p, c3i + t0 * 3, sa_partial, sa_max, points, conf,
+                              heatmap_final, T3, J, Jp, Gh, cfg.grid_spacing, cfg.roi_cube_size, s));
+    return 0;
   }
 };
 
@@ -209,6 +226,8 @@ int jh_predictor_create(const jh_params* center_params, const jh_params* hybrid_
   std::unique_ptr<jh_predictor> pr(new jh_predictor());
   pr->cfg = *cfg;
   pr->T = cfg->time_batch; pr->C = cfg->num_cameras; pr->Cloc = cfg->cam_n;
+  pr->T3 = cfg->time_batch_3d > 0 ? cfg->time_batch_3d : cfg->time_batch;
+  JH_REQUIRE(pr->T3 <= pr->T, "time_batch_3d must not exceed time_batch");
   pr->J = cfg->num_joints; pr->Jp = cpad(cfg->num_joints);
   pr->B = cfg->bbox; pr->Hh = cfg->bbox / 2; pr->hs = cfg->bbox / 2 + 2;
   pr->G = (int)(cfg->roi_cube_size / cfg->grid_spacing);
@@ -225,7 +244,7 @@ int jh_predictor_create(const jh_params* center_params, const jh_params* hybrid_
   pr->kp.reset(new EffTrackPlan());
   if (pr->kp->build(hybrid_params->map, "effTrack.", cfg->kp_model, pr->J, N, pr->B, pr->B)) return 1;
   pr->v2v.reset(new V2VPlan());
-  if (pr->v2v->build(hybrid_params->map, "v2vNet.", pr->J, pr->T, pr->G)) return 1;
+  if (pr->v2v->build(hybrid_params->map, "v2vNet.", pr->J, pr->T3, pr->G)) return 1;
   auto& m = pr->mem;
   const int T = pr->T, C = pr->C;
   if (m.get(reinterpret_cast<void**>(&pr->cam), (size_t)C * 12 * sizeof(float))) return 1;
@@ -237,7 +256,7 @@ int jh_predictor_create(const jh_params* center_params, const jh_params* hybrid_
   if (m.get(reinterpret_cast<void**>(&pr->chm), (size_t)T * C * 2 * sizeof(int))) return 1;
   if (m.get(reinterpret_cast<void**>(&pr->valid), (size_t)T * sizeof(int))) return 1;
   if (m.get(reinterpret_cast<void**>(&pr->coarse),
-            (size_t)T * C * pr->Gh * pr->Gh * pr->Gh * sizeof(float2))) return 1;
+            (size_t)pr->T3 * C * pr->Gh * pr->Gh * pr->Gh * sizeof(float2))) return 1;
   if (m.get(reinterpret_cast<void**>(&pr->sa_partial), (size_t)T * pr->Jp * 4 * sizeof(double))) return 1;
   if (m.get(reinterpret_cast<void**>(&pr->sa_max), (size_t)T * pr->Jp * sizeof(int))) return 1;
   JH_CHECK_HIP(hipMemset(pr->valid, 0, (size_t)T * sizeof(int)));
@@ -271,11 +290,14 @@ int jh_predictor_stage_center(jh_predictor* pr, const float* frames_dev, float* 
   hipStream_t s = static_cast<hipStream_t>(stream);
   JH_REQUIRE(pr->center, "predictor was created without CenterDetect weights");
   const int N = pr->T * pr->Cloc, S = pr->cfg.center_size;
-  if (launch_preprocess_resize(frames_dev, pr->center->input.p, N, pr->cfg.img_h, pr->cfg.img_w, S,
-                               pr->cfg.mean, pr->cfg.std, s)) return 1;
+  JH_PROF("preprocess_resize", 0.0, (double)N * S * S * (12.0 * 4 + 3 * 4),
+          launch_preprocess_resize(frames_dev, pr->center->input.p, N, pr->cfg.img_h, pr->cfg.img_w,
+                                   S, pr->cfg.mean, pr->cfg.std, s));
   if (pr->center->run(s)) return 1;
   const Act& h = pr->center->heat;
-  return launch_center_argmax(h.p, det_dev, N, h.H, h.W, h.Cp, s);
+  JH_PROF("center_argmax", 0.0, 4.0 * N * h.H * h.W,
+          launch_center_argmax(h.p, det_dev, N, h.H, h.W, h.Cp, s));
+  return 0;
 }
 
 int jh_predictor_stage_keypoints(jh_predictor* pr, const float* frames_dev,
@@ -285,14 +307,15 @@ int jh_predictor_stage_keypoints(jh_predictor* pr, const float* frames_dev,
   // preds * (downsampling_scale * 2), jarvis3D.py:138-141,158-160
   const float sx2 = (float)((double)c.img_w / (double)c.center_size) * 2.f;
   const float sy2 = (float)((double)c.img_h / (double)c.center_size) * 2.f;
-  if (launch_triangulate(det_all_dev, pr->cam, pr->intr, pr->dist, pr->c3f, pr->c3i, pr->chm,
-                         pr->valid, pr->T, pr->C, sx2, sy2, 255.f, pr->B / 2, c.img_w, c.img_h, s))
-    return 1;
+  JH_PROF("triangulate", 0.0, 0.0,
+          launch_triangulate(det_all_dev, pr->cam, pr->intr, pr->dist, pr->c3f, pr->c3i, pr->chm,
+                             pr->valid, pr->T, pr->C, sx2, sy2, 255.f, pr->B / 2, c.img_w, c.img_h, s));
   if (det_all_dev != pr->det_all)
     JH_CHECK_HIP(hipMemcpyAsync(pr->det_all, det_all_dev, (size_t)pr->T * pr->C * 3 * sizeof(float),
                                 hipMemcpyDeviceToDevice, s));
-  if (launch_preprocess_crop(frames_dev, pr->chm, pr->kp->input.p, pr->T, pr->Cloc, pr->C, c.cam_lo,
-                             c.img_h, c.img_w, pr->B, c.mean, c.std, s)) return 1;
+  JH_PROF("preprocess_crop", 0.0, (double)pr->T * pr->Cloc * pr->B * pr->B * 24.0,
+          launch_preprocess_crop(frames_dev, pr->chm, pr->kp->input.p, pr->T, pr->Cloc, pr->C,
+                                 c.cam_lo, c.img_h, c.img_w, pr->B, c.mean, c.std, s));
   if (pr->kp->run(s)) return 1;
   if (heat_dev && heat_dev != pr->kp->heat.p)
     JH_CHECK_HIP(hipMemcpyAsync(heat_dev, pr->kp->heat.p, pr->kp->heat.bytes(),
@@ -300,12 +323,13 @@ int jh_predictor_stage_keypoints(jh_predictor* pr, const float* frames_dev,
   return 0;
 }
 
-int jh_predictor_stage_3d(jh_predictor* pr, const float* heat_all_dev, float* points_dev,
+int jh_predictor_stage_3d(jh_predictor* pr, const float* heat_all_dev, int t0, float* points_dev,
                           float* conf_dev, int32_t* valid_dev, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (pr->run_3d(heat_all_dev, nullptr, points_dev, conf_dev, s)) return 1;
+  JH_REQUIRE(t0 >= 0 && t0 + pr->T3 <= pr->T, "frame range of the 3D stage");
+  if (pr->run_3d(heat_all_dev, t0, nullptr, points_dev, conf_dev, s)) return 1;
   if (valid_dev)
-    JH_CHECK_HIP(hipMemcpyAsync(valid_dev, pr->valid, (size_t)pr->T * sizeof(int),
+    JH_CHECK_HIP(hipMemcpyAsync(valid_dev, pr->valid + t0, (size_t)pr->T3 * sizeof(int),
                                 hipMemcpyDeviceToDevice, s));
   return 0;
 }
@@ -313,9 +337,10 @@ int jh_predictor_stage_3d(jh_predictor* pr, const float* heat_all_dev, float* po
 int jh_predictor_forward(jh_predictor* pr, const float* frames_dev, float* points_dev,
                          float* conf_dev, int32_t* valid_dev, void* stream) {
   JH_REQUIRE(pr->Cloc == pr->C && pr->cfg.cam_lo == 0, "forward needs all cameras local");
+  JH_REQUIRE(pr->T3 == pr->T, "forward needs time_batch_3d == time_batch");
   if (jh_predictor_stage_center(pr, frames_dev, pr->det_all, stream)) return 1;
   if (jh_predictor_stage_keypoints(pr, frames_dev, pr->det_all, nullptr, stream)) return 1;
-  return jh_predictor_stage_3d(pr, pr->kp->heat.p, points_dev, conf_dev, valid_dev, stream);
+  return jh_predictor_stage_3d(pr, pr->kp->heat.p, 0, points_dev, conf_dev, valid_dev, stream);
 }
 
 int jh_predictor_debug(jh_predictor* pr, float* center3d_f_dev, int32_t* center3d_i_dev,
@@ -334,7 +359,7 @@ int jh_predictor_hybridnet_forward(jh_predictor* pr, const float* crops_dev,
                                    float* heatmap_final_dev, float* heatmaps_padded_dev,
                                    float* points_dev, float* conf_dev, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
-  JH_REQUIRE(pr->Cloc == pr->C, "hybridnet_forward needs all cameras local");
+  JH_REQUIRE(pr->Cloc == pr->C && pr->T3 == pr->T, "hybridnet_forward needs all cameras local");
   JH_CHECK_HIP(hipMemcpyAsync(pr->chm, center_hm_dev, (size_t)pr->T * pr->C * 2 * sizeof(int), hipMemcpyDeviceToDevice, s));
   JH_CHECK_HIP(hipMemcpyAsync(pr->c3i, center3d_dev, (size_t)pr->T * 3 * sizeof(int), hipMemcpyDeviceToDevice, s));
   if (launch_to_channel_last(crops_dev, pr->kp->input, s)) return 1;
@@ -348,7 +373,35 @@ int jh_predictor_hybridnet_forward(jh_predictor* pr, const float* crops_dev,
                        h.N, pr->J, h.Cp, pr->Hh);
     JH_CHECK_HIP(hipGetLastError());
   }
-  return pr->run_3d(pr->kp->heat.p, heatmap_final_dev, points_dev, conf_dev, s);
+  return pr->run_3d(pr->kp->heat.p, 0, heatmap_final_dev, points_dev, conf_dev, s);
+}
+
+// ------------------------------------------------------------------- profiling
+int jh_profile_begin(void) {
+  Profiler& pf = profiler();
+  pf.recs.clear();
+  pf.on = true;
+  return 0;
+}
+int jh_profile_end(int* n_records) {
+  Profiler& pf = profiler();
+  pf.on = false;
+  if (pf.finish()) return 1;
+  if (n_records) *n_records = (int)pf.recs.size();
+  return 0;
+}
+int jh_profile_get(int i, char* name, int name_cap, double* ms, double* flops, double* bytes) {
+  Profiler& pf = profiler();
+  JH_REQUIRE(i >= 0 && i < (int)pf.recs.size(), "profile record index");
+  const ProfRec& r = pf.recs[i];
+  if (name && name_cap > 0) {
+    strncpy(name, r.name.c_str(), name_cap - 1);
+    name[name_cap - 1] = 0;
+  }
+  if (ms) *ms = r.ms;
+  if (flops) *flops = r.flops;
+  if (bytes) *bytes = r.bytes;
+  return 0;
 }
 
 // -------------------------------------------------------- single-operator tests

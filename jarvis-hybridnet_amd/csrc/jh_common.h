@@ -11,6 +11,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <vector>
 
 namespace jh {
 
@@ -48,6 +49,18 @@ struct Act {
 };
 
 enum ActKind { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2 };
+
+// Optional per-launch timing with HIP events on the launch stream (bench.py's
+// roofline numbers).  Off by default: the hot path records nothing.
+struct ProfRec { std::string name; double flops, bytes; hipEvent_t e0, e1; float ms; };
+struct Profiler {
+  bool on = false;
+  std::vector<ProfRec> recs;
+  void begin(const std::string& name, double flops, double bytes, hipStream_t s);
+  void end(hipStream_t s);
+  int finish();            // synchronise, fill ms, destroy events
+};
+Profiler& profiler();
 
 // ---------------------------------------------------------------- conv (MFMA)
 // One "phase" of a (transposed) convolution: out[o*os + ooff] =

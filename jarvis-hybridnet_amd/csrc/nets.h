@@ -54,7 +54,11 @@ class Plan {
   int upload(const std::vector<float>& host, float** dev);
   int get(const ParamMap& pm, const std::string& key, size_t numel, const float** out);
 
-  std::vector<std::function<int(hipStream_t)>> ops_;
+  struct Op { std::function<int(hipStream_t)> fn; std::string name; double flops, bytes; };
+  std::vector<Op> ops_;
+  void push(const std::string& name, double flops, double bytes, std::function<int(hipStream_t)> fn) {
+    ops_.push_back(Op{std::move(fn), name, flops, bytes});
+  }
   std::vector<void*> owned_;
   std::vector<ConvWeights> convs_;
   double* arena_ = nullptr;

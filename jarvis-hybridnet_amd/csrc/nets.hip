@@ -8,6 +8,31 @@
 
 namespace jh {
 
+// -------------------------------------------------------------------- Profiler
+Profiler& profiler() {
+  static Profiler p;
+  return p;
+}
+void Profiler::begin(const std::string& name, double flops, double bytes, hipStream_t s) {
+  ProfRec r{name, flops, bytes, nullptr, nullptr, 0.f};
+  (void)hipEventCreate(&r.e0);
+  (void)hipEventCreate(&r.e1);
+  (void)hipEventRecord(r.e0, s);
+  recs.push_back(r);
+}
+void Profiler::end(hipStream_t s) { (void)hipEventRecord(recs.back().e1, s); }
+int Profiler::finish() {
+  JH_CHECK_HIP(hipDeviceSynchronize());
+  for (auto& r : recs) {
+    if (!r.e0) continue;
+    JH_CHECK_HIP(hipEventElapsedTime(&r.ms, r.e0, r.e1));
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+    r.e0 = r.e1 = nullptr;
+  }
+  return 0;
+}
+
 // ------------------------------------------------------------------------ Plan
 Plan::~Plan() {
   for (void* p : owned_) (void)hipFree(p);
@@ -42,8 +67,12 @@ int Plan::finish() {
 
 int Plan::run(hipStream_t s) {
   JH_CHECK_HIP(hipMemsetAsync(arena_, 0, arena_doubles_ * sizeof(double), s));
-  for (auto& op : ops_)
-    if (op(s)) return 1;
+  Profiler& pf = profiler();
+  for (auto& op : ops_) {
+    if (pf.on) pf.begin(op.name, op.flops, op.bytes, s);
+    if (op.fn(s)) return 1;
+    if (pf.on) pf.end(s);
+  }
   return 0;
 }
 
@@ -79,7 +108,16 @@ int Plan::add_conv(const ParamMap& pm, const ConvDesc& d, const std::string& wke
     off = scratch((size_t)y.N * y.Cp * 2);
     if (stats_off) *stats_off = off;
   }
-  ops_.push_back([this, d, cw, x, y, gate, want_stats, off](hipStream_t s) {
+  // algorithmic work: 2*MAC over the real (unpadded) channels; bytes = one read of
+  // the input, one write of the output, one read of the weights
+  const double opix = (double)y.N * y.pixels();
+  const double taps_per_out = (d.ostride > 1) ? (double)taps / d.nphase : (double)taps;
+  const double flops = 2.0 * opix * d.cin * d.cout * taps_per_out;
+  const double bytes = 4.0 * ((double)x.N * x.pixels() * d.cin + opix * d.cout + (double)d.cin * d.cout * taps);
+  char nm[96];
+  snprintf(nm, sizeof nm, "conv%dd_k%ds%d%s_%dx%d@%d", d.nd, d.ostride > 1 ? (d.nd == 2 ? 4 : 2) : d.k,
+           d.ostride > 1 ? 2 : d.stride, d.ostride > 1 ? "T" : "", d.cin, d.cout, y.W);
+  push(nm, flops, bytes, [this, d, cw, x, y, gate, want_stats, off](hipStream_t s) {
     return launch_conv(d, cw, x, y, gate, want_stats ? sc(off) : nullptr, s);
   });
   return 0;
@@ -87,7 +125,9 @@ int Plan::add_conv(const ParamMap& pm, const ConvDesc& d, const std::string& wke
 
 void Plan::add_norm(const Act& x, size_t stats_off, int act, const float* r1, const float* r2,
                     float* y, long pool_off) {
-  ops_.push_back([this, x, stats_off, act, r1, r2, y, pool_off](hipStream_t s) {
+  const double el = (double)x.N * x.pixels() * x.C;
+  push("norm_apply", 8.0 * el, 4.0 * el * (2 + (r1 ? 1 : 0) + (r2 ? 1 : 0)),
+       [this, x, stats_off, act, r1, r2, y, pool_off](hipStream_t s) {
     return launch_norm_apply(x, sc(stats_off), 1e-5f, act, r1, r2, y,
                              pool_off >= 0 ? sc((size_t)pool_off) : nullptr, s);
   });
@@ -167,7 +207,8 @@ int EffTrackPlan::mbconv(const ParamMap& pm, const std::string& p, int stage, in
     float* wd = nullptr;
     if (upload(wt, &wd)) return 1;
     st1 = scratch((size_t)raw.N * raw.Cp * 2);
-    ops_.push_back([this, e, wd, k, raw, st1](hipStream_t s) {
+    push("depthwise_k" + std::to_string(k), 2.0 * raw.N * raw.pixels() * mid * k * k,
+         8.0 * raw.N * raw.pixels() * mid, [this, e, wd, k, raw, st1](hipStream_t s) {
       return launch_depthwise(e, wd, k, raw.p, sc(st1), s);
     });
   }
@@ -187,7 +228,8 @@ int EffTrackPlan::mbconv(const ParamMap& pm, const std::string& p, int stage, in
   if (upload(std::vector<float>(be, be + mid), &dbe)) return 1;
   if (alloc(reinterpret_cast<void**>(&gate), (size_t)raw.N * raw.Cp * sizeof(float))) return 1;
   const float inv_hw = 1.f / (float)(Ho * Wo);
-  ops_.push_back([this, pool, raw, mid, squeeze, inv_hw, dwr, dbr, dwe, dbe, gate](hipStream_t s) {
+  push("se_gate", 4.0 * raw.N * mid * squeeze, 8.0 * raw.N * mid,
+       [this, pool, raw, mid, squeeze, inv_hw, dwr, dbr, dwe, dbe, gate](hipStream_t s) {
     return launch_se_gate(sc(pool), raw.N, mid, raw.Cp, squeeze, inv_hw, dwr, dbr, dwe, dbe, gate, s);
   });
   // project (gate applied while staging the operand) + _gn2 (+ skip)
@@ -213,7 +255,8 @@ int EffTrackPlan::sepconv(const ParamMap& pm, const std::string& p, int cout, co
   if (upload(wt, &wd)) return 1;
   Act dw;
   if (new_act(x.N, 1, x.H, x.W, x.C, &dw)) return 1;
-  ops_.push_back([x, wd, dw](hipStream_t s) { return launch_depthwise(x, wd, 3, dw.p, nullptr, s); });
+  push("depthwise_k3", 18.0 * x.N * x.pixels() * x.C, 8.0 * x.N * x.pixels() * x.C,
+       [x, wd, dw](hipStream_t s) { return launch_depthwise(x, wd, 3, dw.p, nullptr, s); });
   if (new_act(x.N, 1, x.H, x.W, cout, out)) return 1;
   size_t st = 0;
   if (add_conv(pm, conv_desc(2, 1, 1, 0, x.C, cout), p + "pointwise_conv.weight",
@@ -240,7 +283,8 @@ int EffTrackPlan::fuse(int n_in, const Act* ins, const int* modes, const float* 
   f.n_in = n_in; f.act = act;
   for (int i = 0; i < n_in; ++i) { f.in[i] = ins[i].p; f.mode[i] = modes[i]; f.w[i] = w[i]; }
   const Act o = *out;
-  ops_.push_back([f, o](hipStream_t s) { return launch_fuse(f, o, s); });
+  push("bifpn_fuse", 2.0 * n_in * o.N * o.pixels() * o.C, 4.0 * (n_in + 1) * o.N * o.pixels() * o.C,
+       [f, o](hipStream_t s) { return launch_fuse(f, o, s); });
   return 0;
 }
 
@@ -287,9 +331,9 @@ int EffTrackPlan::build(const ParamMap& pm, const std::string& pre, int size, in
       Act t6;
       if (lateral(pm, p + "p5_to_p6", Wf, feats[2], &t6)) return 1;
       if (new_act(N, 1, t6.H / 2, t6.W / 2, Wf, &p6_in)) return 1;
-      { const Act a = t6, o = p6_in; ops_.push_back([a, o](hipStream_t s) { return launch_maxpool2(a, o.p, s); }); }
+      { const Act a = t6, o = p6_in; push("maxpool2", 0, 5.0 * o.N * o.pixels() * o.C * 4, [a, o](hipStream_t s) { return launch_maxpool2(a, o.p, s); }); }
       if (new_act(N, 1, p6_in.H / 2, p6_in.W / 2, Wf, &p7_in)) return 1;
-      { const Act a = p6_in, o = p7_in; ops_.push_back([a, o](hipStream_t s) { return launch_maxpool2(a, o.p, s); }); }
+      { const Act a = p6_in, o = p7_in; push("maxpool2", 0, 5.0 * o.N * o.pixels() * o.C * 4, [a, o](hipStream_t s) { return launch_maxpool2(a, o.p, s); }); }
       if (lateral(pm, p + "p3_down_channel", Wf, feats[0], &p3_in)) return 1;
       if (lateral(pm, p + "p4_down_channel", Wf, feats[1], &p4_in)) return 1;
       if (lateral(pm, p + "p5_down_channel", Wf, feats[2], &p5_in)) return 1;

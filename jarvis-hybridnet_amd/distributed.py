@@ -1,0 +1,87 @@
+"""Camera-sharded multi-GPU execution of the hot path (one process per GPU,
+torch.distributed with the RCCL backend over xGMI).
+
+The reference has no distributed code at all; this is
+new design for the 8 x MI355X node:
+
+  rank r owns cameras [r*C/N, (r+1)*C/N) for the 2D work of all T frames of a
+  time batch, and frames [r*T/N, (r+1)*T/N) for the 3D work.
+
+  stage 1   resize + CenterDetect + argmax on the owned cameras
+  exchange  all-gather of (x, y, maxval) per camera           (T*C*12 bytes)
+  stage 2   every rank triangulates redundantly (identical inputs, so identical
+            results, no broadcast), crops + KeypointDetect on the owned cameras
+  exchange  heatmaps: rank r needs all cameras of ITS frames, so the exchange is
+            an all-to-all of (T/N, C/N, h, w, Jp) blocks -- 1/N of the volume of
+            the all-gather it replaces.  xGMI is a full mesh of point-to-point
+            links, so every block travels one hop on its own link.  The literal
+            all-gather (every rank receives everything) is kept as
+            exchange='allgather' for comparison.
+  stage 3   reprojection + V2V + soft-argmax for the owned frames
+  gather    (T/N, J, 4) results to every rank (tiny all-gather)
+
+`stages` is any object with the four methods used below, which is what lets the
+world_size-2 gloo test on CPU drive this file with the oracle as compute.
+"""
+import torch
+import torch.distributed as dist
+
+
+def camera_range(num_cameras, rank, world):
+    assert num_cameras % world == 0, "cameras must divide evenly over the ranks"
+    n = num_cameras // world
+    return rank * n, n
+
+
+def frame_range(time_batch, rank, world):
+    assert time_batch % world == 0, "time batch must divide evenly over the ranks"
+    n = time_batch // world
+    return rank * n, n
+
+
+class ShardedPredictor:
+    def __init__(self, stages, *, num_cameras, num_joints, time_batch, heat_shape, rank, world,
+                 device, exchange="alltoall", group=None):
+        """heat_shape = (h, w, Jp) of one camera's channel-last heatmap."""
+        self.st, self.C, self.J, self.T = stages, num_cameras, num_joints, time_batch
+        self.rank, self.world, self.group, self.exchange = rank, world, group, exchange
+        self.cam_lo, self.Cloc = camera_range(num_cameras, rank, world)
+        self.t_lo, self.T3 = frame_range(time_batch, rank, world)
+        f32 = dict(device=device, dtype=torch.float32)
+        self.det_local = torch.empty((self.T, self.Cloc, 3), **f32)
+        self.det_gather = torch.empty((world, self.T, self.Cloc, 3), **f32)
+        self.heat_local = torch.empty((self.T, self.Cloc) + tuple(heat_shape), **f32)
+        if exchange == "alltoall":
+            self.heat_recv = torch.empty((world, self.T3, self.Cloc) + tuple(heat_shape), **f32)
+        else:
+            self.heat_recv = torch.empty((world, self.T, self.Cloc) + tuple(heat_shape), **f32)
+        self.res_local = torch.empty((self.T3, self.J, 4), **f32)
+        self.res_all = torch.empty((world, self.T3, self.J, 4), **f32)
+        self.valid_local = torch.empty((self.T3,), device=device, dtype=torch.int32)
+        self.valid_all = torch.empty((world, self.T3), device=device, dtype=torch.int32)
+
+    def step(self, frames_local):
+        """frames_local (T, Cloc, 3, H, W) -> points (T,J,3), conf (T,J), valid (T)."""
+        W, T3, Cl = self.world, self.T3, self.Cloc
+        self.st.stage_center(frames_local, self.det_local)
+        dist.all_gather_into_tensor(self.det_gather, self.det_local, group=self.group)
+        det_all = self.det_gather.permute(1, 0, 2, 3).reshape(self.T, self.C, 3).contiguous()
+        self.st.stage_keypoints(frames_local, det_all, self.heat_local)
+        if self.exchange == "alltoall":
+            # block r of the send buffer = my cameras' heatmaps of rank r's frames
+            dist.all_to_all_single(self.heat_recv, self.heat_local, group=self.group)
+            mine = self.heat_recv
+        else:
+            dist.all_gather_into_tensor(self.heat_recv, self.heat_local, group=self.group)
+            mine = self.heat_recv[:, self.t_lo:self.t_lo + T3]
+        # (world, T3, Cloc, ...) -> (T3, C, ...): camera c = source_rank * Cloc + local camera
+        heat_all = mine.permute(1, 0, 2, 3, 4, 5).reshape((T3, self.C) + mine.shape[3:]).contiguous()
+        pts = torch.empty((T3, self.J, 3), device=heat_all.device)
+        conf = torch.empty((T3, self.J), device=heat_all.device)
+        self.st.stage_3d(heat_all, self.t_lo, pts, conf, self.valid_local)
+        self.res_local[..., :3] = pts
+        self.res_local[..., 3] = conf
+        dist.all_gather_into_tensor(self.res_all, self.res_local, group=self.group)
+        dist.all_gather_into_tensor(self.valid_all, self.valid_local, group=self.group)
+        res = self.res_all.reshape(self.T, self.J, 4)
+        return res[..., :3], res[..., 3], self.valid_all.reshape(self.T)

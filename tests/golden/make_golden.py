@@ -151,6 +151,10 @@ def case_reprojection():
         full = ref_vol.numel() <= 1 << 16
         put(out, tag + ".idx", ref_idx, full)
         put(out, tag + ".vol", ref_vol, full)
+        if not full and ref_idx.numel() <= 4e6:
+            # the complete integer index field, delta-coded along the last axis
+            a = ref_idx.numpy().astype(np.int16)
+            out[tag + ".idx_delta16"] = np.diff(a, axis=-1, prepend=np.int16(0)).astype(np.int16)
         frac = float((ref_vol > 1).float().mean())
         print(tag, "ok", tuple(ref_vol.shape), "max %.1f  frac>1 %.3f" %
               (float(ref_vol.max()), frac))
@@ -344,7 +348,16 @@ ALL = dict(state_spec=case_state_spec, efficienttrack=case_efficienttrack,
            reprojection=case_reprojection, v2v=case_v2v, geometry=case_geometry,
            hybridnet=case_hybridnet, predictor=case_predictor)
 
+def cpu_model():
+    for line in open("/proc/cpuinfo"):
+        if line.startswith("model name"):
+            return line.split(":", 1)[1].strip()
+    return "unknown"
+
+
 if __name__ == "__main__":
+    with open(os.path.join(HERE, "environment.json"), "w") as f:
+        json.dump(dict(cpu=cpu_model(), torch=torch.__version__), f)
     names = sys.argv[1:] or list(ALL)
     for n in names:
         t0 = time.time()

@@ -27,3 +27,29 @@ def check_summary(g, name, t, rtol=0.0, atol=0.0):
         np.testing.assert_allclose(flat[::step], sample, rtol=rtol, atol=atol)
         scale = float(g[name + ".abssum"])
         assert abs(flat.sum() - float(g[name + ".sum"])) <= rtol * scale + atol * flat.size
+
+
+def golden_indices(g, tag):
+    """Full reference gather-index tensor (C,G,G,G) of a reprojection case, or
+    None when only samples were stored."""
+    key = tag + ".idx_delta16"
+    if tag + ".idx" in g:
+        return torch.from_numpy(g[tag + ".idx"]).long()
+    if key not in g:
+        return None
+    return torch.from_numpy(np.cumsum(g[key].astype(np.int64), axis=-1))
+
+
+def same_cpu_as_golden():
+    """True when this machine's CPU model is the one the fixtures were made on
+    (torch's CPU kernels, hence the oracle's last bits, depend on the ISA)."""
+    import json
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = json.load(open(os.path.join(here, "golden", "environment.json")))
+    model = "unknown"
+    for line in open("/proc/cpuinfo"):
+        if line.startswith("model name"):
+            model = line.split(":", 1)[1].strip()
+            break
+    return model == env["cpu"]
