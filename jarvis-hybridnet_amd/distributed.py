@@ -49,31 +49,35 @@ class ShardedPredictor:
         self.t_lo, self.T3 = frame_range(time_batch, rank, world)
         f32 = dict(device=device, dtype=torch.float32)
         self.det_local = torch.empty((self.T, self.Cloc, 3), **f32)
-        self.det_gather = torch.empty((world, self.T, self.Cloc, 3), **f32)
+        # gather outputs are allocated in the "concatenated along dim 0" form that both
+        # RCCL and gloo accept, and viewed as (world, ...) afterwards
+        self.det_gather = torch.empty((world * self.T, self.Cloc, 3), **f32)
         self.heat_local = torch.empty((self.T, self.Cloc) + tuple(heat_shape), **f32)
         if exchange == "alltoall":
-            self.heat_recv = torch.empty((world, self.T3, self.Cloc) + tuple(heat_shape), **f32)
+            self.heat_recv = torch.empty((world * self.T3, self.Cloc) + tuple(heat_shape), **f32)
         else:
-            self.heat_recv = torch.empty((world, self.T, self.Cloc) + tuple(heat_shape), **f32)
+            self.heat_recv = torch.empty((world * self.T, self.Cloc) + tuple(heat_shape), **f32)
         self.res_local = torch.empty((self.T3, self.J, 4), **f32)
-        self.res_all = torch.empty((world, self.T3, self.J, 4), **f32)
+        self.res_all = torch.empty((world * self.T3, self.J, 4), **f32)
         self.valid_local = torch.empty((self.T3,), device=device, dtype=torch.int32)
-        self.valid_all = torch.empty((world, self.T3), device=device, dtype=torch.int32)
+        self.valid_all = torch.empty((world * self.T3,), device=device, dtype=torch.int32)
 
     def step(self, frames_local):
         """frames_local (T, Cloc, 3, H, W) -> points (T,J,3), conf (T,J), valid (T)."""
         W, T3, Cl = self.world, self.T3, self.Cloc
         self.st.stage_center(frames_local, self.det_local)
         dist.all_gather_into_tensor(self.det_gather, self.det_local, group=self.group)
-        det_all = self.det_gather.permute(1, 0, 2, 3).reshape(self.T, self.C, 3).contiguous()
+        det_all = (self.det_gather.view(W, self.T, Cl, 3).permute(1, 0, 2, 3)
+                   .reshape(self.T, self.C, 3).contiguous())
         self.st.stage_keypoints(frames_local, det_all, self.heat_local)
         if self.exchange == "alltoall":
             # block r of the send buffer = my cameras' heatmaps of rank r's frames
             dist.all_to_all_single(self.heat_recv, self.heat_local, group=self.group)
-            mine = self.heat_recv
+            mine = self.heat_recv.view((W, T3, Cl) + self.heat_recv.shape[2:])
         else:
             dist.all_gather_into_tensor(self.heat_recv, self.heat_local, group=self.group)
-            mine = self.heat_recv[:, self.t_lo:self.t_lo + T3]
+            mine = self.heat_recv.view((W, self.T, Cl) + self.heat_recv.shape[2:])[
+                :, self.t_lo:self.t_lo + T3]
         # (world, T3, Cloc, ...) -> (T3, C, ...): camera c = source_rank * Cloc + local camera
         heat_all = mine.permute(1, 0, 2, 3, 4, 5).reshape((T3, self.C) + mine.shape[3:]).contiguous()
         pts = torch.empty((T3, self.J, 3), device=heat_all.device)
