@@ -1,0 +1,277 @@
+// One BiFPN node as ONE kernel:
+//
+//   out_raw = pointwise( depthwise3x3( act( sum_i w_i * resample_i( IN_i(in_i) ) ) ) ) + bias
+//
+// i.e. the fast-normalised fusion (incl. nearest upsampling / 2x2 max-pooling of the
+// neighbour level and the InstanceNorm of every input, applied on load from the
+// producer's fused statistics), the SiLU, the SeparableConvBlock's depthwise 3x3 and
+// its 1x1 pointwise convolution with bias, plus the statistics of the output for the
+// InstanceNorm that follows.  Replaces, per node, jarvis/efficienttrack/model.py:
+// 309-353 (fusion expressions) + :223-232 (SeparableConvBlock.forward) and the head
+// expression :119-126.  Unfused this was fuse + depthwise + pointwise + norm_apply =
+// 9 passes over a P3-sized tensor; fused it is (n_in reads + 1 write).
+//
+// Tile: 8 x 16 output pixels per workgroup of 512 threads (8 waves x 1 row block of
+// 16 pixels; 8 waves because the prologue is latency-bound and LDS limits the CU to
+// 3 workgroups).
+//   1. mean / rstd of every normalised input -> LDS
+//   2. per channel chunk: fused + activated halo tile (10 x 18 pixels) -> LDS F,
+//      depthwise 3x3 from F -> LDS operand tile A[128][Cp + 4]
+//   3. MFMA 16x16x4 fp32 over K = Cp for 4 output-channel blocks at a time
+//      (weights streamed from L2 in packed B-operand order), shared epilogue.
+#include <cstdlib>
+#include "conv_mfma.h"
+#include "bifpn_node.h"
+
+namespace jh {
+
+constexpr int kNodeTY = 8, kNodeTX = 16, kNodePY = 10, kNodePX = 18, kNodeNRG = 4;
+
+__device__ __forceinline__ float4 node_fetch(const float* in, int mode, int n, int oy, int ox, int H,
+                                             int W, int Cp, int c) {
+  if (mode == FUSE_SAME)
+    return *reinterpret_cast<const float4*>(in + (((size_t)n * H + oy) * W + ox) * Cp + c);
+  if (mode == FUSE_UP2) {
+    const int h = H >> 1, w = W >> 1;
+    return *reinterpret_cast<const float4*>(in + (((size_t)n * h + (oy >> 1)) * w + (ox >> 1)) * Cp + c);
+  }
+  if (mode == FUSE_UP4) {
+    const int h = H >> 2, w = W >> 2;
+    return *reinterpret_cast<const float4*>(in + (((size_t)n * h + (oy >> 2)) * w + (ox >> 2)) * Cp + c);
+  }
+  const int h = H * 2, w = W * 2;     // FUSE_POOL2 (max commutes with the monotone IN map)
+  const float* b = in + (((size_t)n * h + oy * 2) * w + ox * 2) * Cp + c;
+  const float4 a0 = *reinterpret_cast<const float4*>(b);
+  const float4 a1 = *reinterpret_cast<const float4*>(b + Cp);
+  const float4 a2 = *reinterpret_cast<const float4*>(b + (size_t)w * Cp);
+  const float4 a3 = *reinterpret_cast<const float4*>(b + (size_t)w * Cp + Cp);
+  return make_float4(fmaxf(fmaxf(a0.x, a1.x), fmaxf(a2.x, a3.x)), fmaxf(fmaxf(a0.y, a1.y), fmaxf(a2.y, a3.y)),
+                     fmaxf(fmaxf(a0.z, a1.z), fmaxf(a2.z, a3.z)), fmaxf(fmaxf(a0.w, a1.w), fmaxf(a2.w, a3.w)));
+}
+
+__device__ __forceinline__ float node_act(float v, int act) {
+  if (act == ACT_SILU) return v / (1.f + expf(-v));
+  if (act == ACT_RELU) return fmaxf(v, 0.f);
+  return v;
+}
+
+// The resampling modes are template parameters: with them known at compile time the
+// halo loads of several items can be issued back to back (no data-dependent branches),
+// which is what hides the HBM latency of this otherwise latency-bound prologue.
+template <int NIN, int M0, int M1, int M2>
+__global__ __launch_bounds__(512) void bifpn_node_kernel(const NodeArgs a) {
+  constexpr int kModes[3] = {M0, M1, M2};
+  constexpr int U = 2;                           // items in flight per thread
+  constexpr int NT = 512;                        // threads
+  constexpr int KPRE = 8;                        // 8-channel steps whose weights are preloaded
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int Cp = a.Cp;
+  const int SA = Cp + 4;                         // operand tile stride (floats)
+  const int SF = a.cf + 4;                       // halo tile stride
+  float* mr_ = lds;                              // [3][Cp][2] mean, rstd
+  float* dwl = mr_ + 3 * Cp * 2;                 // [9][Cp] depthwise weights
+  float* At = dwl + 9 * Cp;                      // [128][SA]
+  float* Ft = At + 128 * SA;                     // [180][SF]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, mrow = lane & 15, kq = lane >> 4;
+  const int tiles_x = (a.W + kNodeTX - 1) / kNodeTX;
+  const int tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
+  const int n = blockIdx.y;
+  const int oy0 = tile_y * kNodeTY, ox0 = tile_x * kNodeTX;
+
+  // 0. pointwise weights of the first column-block group: issued now, consumed in
+  // step 3, so their L2 latency hides behind the whole prologue
+  const int nk8 = Cp >> 3, nb = a.cout_p16 >> 4;
+  const float2* wl = reinterpret_cast<const float2*>(a.pw) + lane;
+  float2 bpre[KPRE][kNodeNRG];
+  const bool pre = nk8 <= KPRE;
+  if (pre) {
+#pragma unroll
+    for (int k8 = 0; k8 < KPRE; ++k8)
+#pragma unroll
+      for (int nr = 0; nr < kNodeNRG; ++nr)
+        bpre[k8][nr] = wl[(size_t)min(k8, nk8 - 1) * nb * 64 + min(nr, nb - 1) * 64];
+  }
+  for (int i = tid; i < 9 * Cp; i += NT) dwl[i] = a.dw[i];
+
+  // 1. statistics -> mean / rstd (biased variance, eps 1e-5) of every normalised input
+  for (int i = tid; i < a.n_in * Cp; i += NT) {
+    const int k = i / Cp, c = i % Cp;
+    float mean = 0.f, rstd = 1.f;
+    if (a.st[k]) {
+      const double* st = a.st[k] + ((size_t)n * Cp + c) * 2;
+      const double mu = st[0] * (double)a.inv_cnt[k];
+      double var = st[1] * (double)a.inv_cnt[k] - mu * mu;
+      if (var < 0.0) var = 0.0;
+      mean = (float)mu;
+      rstd = (float)(1.0 / sqrt(var + 1e-5));
+    }
+    mr_[(k * Cp + c) * 2 + 0] = mean;
+    mr_[(k * Cp + c) * 2 + 1] = rstd;
+  }
+  __syncthreads();
+
+  // 2. fused halo tile -> depthwise -> operand tile, one channel chunk at a time
+  for (int cf0 = 0; cf0 < Cp; cf0 += a.cf) {
+    const int cw = min(a.cf, Cp - cf0);          // multiple of 4
+    const int q = cw >> 2;
+    const int total = kNodePY * kNodePX * q;
+    for (int base = tid; base < total; base += NT * U) {
+      float4 v[U][NIN];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int idx = base + u * NT;
+        const int c4 = idx % q, pix = idx / q;
+        const int px = pix % kNodePX, py = pix / kNodePX;
+        const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+        ok[u] = idx < total && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+#pragma unroll
+        for (int k = 0; k < NIN; ++k)
+          v[u][k] = ok[u] ? node_fetch(a.in[k], kModes[k], n, iy, ix, a.H, a.W, Cp, cf0 + c4 * 4)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int idx = base + u * NT;
+        if (idx >= total) break;
+        const int c4 = idx % q, pix = idx / q;
+        const int c = cf0 + c4 * 4;
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok[u]) {
+#pragma unroll
+          for (int k = 0; k < NIN; ++k) {
+            float4 x = v[u][k];
+            const float* m = mr_ + (k * Cp + c) * 2;
+            x.x = (x.x - m[0]) * m[1]; x.y = (x.y - m[2]) * m[3];
+            x.z = (x.z - m[4]) * m[5]; x.w = (x.w - m[6]) * m[7];
+            const float wk = a.w[k];
+            if (k == 0) {
+              r = make_float4(__fmul_rn(wk, x.x), __fmul_rn(wk, x.y), __fmul_rn(wk, x.z), __fmul_rn(wk, x.w));
+            } else {
+              r.x = __fadd_rn(r.x, __fmul_rn(wk, x.x)); r.y = __fadd_rn(r.y, __fmul_rn(wk, x.y));
+              r.z = __fadd_rn(r.z, __fmul_rn(wk, x.z)); r.w = __fadd_rn(r.w, __fmul_rn(wk, x.w));
+            }
+          }
+          r.x = node_act(r.x, a.act); r.y = node_act(r.y, a.act);
+          r.z = node_act(r.z, a.act); r.w = node_act(r.w, a.act);
+        }
+        *reinterpret_cast<float4*>(Ft + pix * SF + c4 * 4) = r;
+      }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 128 * q; idx += NT) {
+      const int c4 = idx % q, p = idx / q;
+      const int tx = p % kNodeTX, ty = p / kNodeTX;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const float4 v = *reinterpret_cast<const float4*>(Ft + ((ty + dy) * kNodePX + tx + dx) * SF + c4 * 4);
+          const float4 k = *reinterpret_cast<const float4*>(dwl + (dy * 3 + dx) * Cp + cf0 + c4 * 4);
+          acc.x = fmaf(v.x, k.x, acc.x); acc.y = fmaf(v.y, k.y, acc.y);
+          acc.z = fmaf(v.z, k.z, acc.z); acc.w = fmaf(v.w, k.w, acc.w);
+        }
+      *reinterpret_cast<float4*>(At + p * SA + cf0 + c4 * 4) = acc;
+    }
+    __syncthreads();
+  }
+
+  // 3. pointwise convolution on the matrix cores: wave w owns pixel rows 16w .. 16w+15
+  const float2* A2 = reinterpret_cast<const float2*>(At);
+  const int SA2 = SA >> 1;
+  const int abase = (wave * 16 + mrow) * SA2 + kq;
+  EpilogueArgs e;
+  e.y = a.y + (size_t)n * a.H * a.W * a.cout_p;
+  e.bias = a.bias;
+  e.stats = a.stats ? a.stats + (size_t)n * a.cout_p * 2 : nullptr;
+  e.Dout = 1; e.Hout = a.H; e.Wout = a.W; e.Hy = a.H; e.Wy = a.W;
+  e.cout_p = a.cout_p; e.cout_p16 = a.cout_p16; e.os = 1; e.offz = e.offy = e.offx = 0;
+  for (int nb0 = 0; nb0 < nb; nb0 += kNodeNRG) {
+    f32x4 acc[1][kNodeNRG];
+#pragma unroll
+    for (int nr = 0; nr < kNodeNRG; ++nr) acc[0][nr] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (pre && nb0 == 0) {
+#pragma unroll
+      for (int k8 = 0; k8 < KPRE; ++k8) {
+        if (k8 < nk8) {
+          const float2 ac = A2[abase + k8 * 4];
+#pragma unroll
+          for (int nr = 0; nr < kNodeNRG; ++nr)
+            acc[0][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac.x, bpre[k8][nr].x, acc[0][nr], 0, 0, 0);
+#pragma unroll
+          for (int nr = 0; nr < kNodeNRG; ++nr)
+            acc[0][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac.y, bpre[k8][nr].y, acc[0][nr], 0, 0, 0);
+        }
+      }
+    } else {
+      int boff[kNodeNRG];
+#pragma unroll
+      for (int nr = 0; nr < kNodeNRG; ++nr) boff[nr] = min(nb0 + nr, nb - 1) * 64;
+      float2 bn[kNodeNRG];
+#pragma unroll
+      for (int nr = 0; nr < kNodeNRG; ++nr) bn[nr] = wl[boff[nr]];
+      for (int k8 = 0; k8 < nk8; ++k8) {
+        float2 bc[kNodeNRG];
+        const float2 ac = A2[abase + k8 * 4];
+        const float2* wn = wl + (size_t)min(k8 + 1, nk8 - 1) * nb * 64;
+#pragma unroll
+        for (int nr = 0; nr < kNodeNRG; ++nr) { bc[nr] = bn[nr]; bn[nr] = wn[boff[nr]]; }
+#pragma unroll
+        for (int nr = 0; nr < kNodeNRG; ++nr)
+          acc[0][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac.x, bc[nr].x, acc[0][nr], 0, 0, 0);
+#pragma unroll
+        for (int nr = 0; nr < kNodeNRG; ++nr)
+          acc[0][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac.y, bc[nr].y, acc[0][nr], 0, 0, 0);
+      }
+    }
+    __syncthreads();          // Ft is reused as the reduction scratch of the epilogue
+    conv_epilogue<1, kNodeNRG, kNodeTY, kNodeTX, 8>(acc, e, Ft, nb0, 0, oy0, ox0, tid);
+    __syncthreads();
+  }
+}
+
+template <int NIN, int M0, int M1, int M2>
+static int launch_node_variant(const NodeArgs& a, size_t lds, hipStream_t s) {
+  auto kern = bifpn_node_kernel<NIN, M0, M1, M2>;
+  static bool big = false;
+  if (lds > 64 * 1024 && !big) {
+    JH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    big = true;
+  }
+  const int tiles = ((a.H + kNodeTY - 1) / kNodeTY) * ((a.W + kNodeTX - 1) / kNodeTX);
+  hipLaunchKernelGGL(kern, dim3(tiles, a.N), dim3(512), lds, s, a);
+  JH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_bifpn_node(const NodeArgs& args, hipStream_t s) {
+  NodeArgs a = args;
+  // halo chunk: as many channels as keep the whole workgroup under the LDS budget
+  // (3 workgroups per CU for the 56-channel pyramid of the small model)
+  const size_t fixed = ((size_t)3 * a.Cp * 2 + (size_t)9 * a.Cp + (size_t)128 * (a.Cp + 4)) * sizeof(float);
+  size_t budget = 52 * 1024;
+  if (const char* e = getenv("JH_NODE_LDS_KB")) budget = (size_t)atoi(e) * 1024;
+  if (fixed + (size_t)kNodePY * kNodePX * 12 * sizeof(float) > budget) budget = 78 * 1024;
+  if (fixed + (size_t)kNodePY * kNodePX * 12 * sizeof(float) > budget) budget = 156 * 1024;
+  int cf = a.Cp;
+  while (cf > 8 && fixed + (size_t)kNodePY * kNodePX * (cf + 4) * sizeof(float) > budget) cf -= 4;
+  a.cf = cf;
+  const size_t lds = fixed + (size_t)kNodePY * kNodePX * (cf + 4) * sizeof(float);
+  const size_t red = (size_t)8 * kNodeNRG * 16 * 2 * sizeof(float);
+  JH_REQUIRE((size_t)kNodePY * kNodePX * (cf + 4) * sizeof(float) >= red, "halo chunk too small");
+  JH_REQUIRE(lds <= 160 * 1024, "BiFPN node does not fit LDS");
+  const int m0 = a.mode[0], m1 = a.mode[1], m2 = a.mode[2];
+  JH_REQUIRE(m0 == FUSE_SAME, "first input of a node is at the node's own level");
+  if (a.n_in == 2 && m1 == FUSE_UP2) return launch_node_variant<2, FUSE_SAME, FUSE_UP2, 0>(a, lds, s);
+  if (a.n_in == 2 && m1 == FUSE_POOL2) return launch_node_variant<2, FUSE_SAME, FUSE_POOL2, 0>(a, lds, s);
+  if (a.n_in == 3 && m1 == FUSE_SAME && m2 == FUSE_POOL2)
+    return launch_node_variant<3, FUSE_SAME, FUSE_SAME, FUSE_POOL2>(a, lds, s);
+  if (a.n_in == 3 && m1 == FUSE_UP2 && m2 == FUSE_UP4)
+    return launch_node_variant<3, FUSE_SAME, FUSE_UP2, FUSE_UP4>(a, lds, s);
+  JH_REQUIRE(false, "unsupported BiFPN node variant");
+}
+
+}  // namespace jh

@@ -1,6 +1,7 @@
 // Host side of the MFMA convolution: descriptors, weight packing, dispatch.
 #include <vector>
 #include <cstring>
+#include <cstdlib>
 #include "conv_mfma.h"
 
 namespace jh {
@@ -152,7 +153,11 @@ int launch_conv(const ConvDesc& d, const ConvWeights& w, const Act& x, const Act
     // small tile when the volume would otherwise give fewer blocks than CUs
     const long tiles_big = (long)((a.Dout + 1) / 2) * ((a.Hout + 3) / 4) * ((a.Wout + 15) / 16) *
                            a.N * a.nphase * ((w.cout_p16 / 16 + nr - 1) / nr);
-    const int small = tiles_big < 512 ? 1 : 0;
+    int small = tiles_big < 512 ? 1 : 0;
+    // 256-voxel tiles (4 row blocks per wave: half the weight traffic per MFMA, 2.5x
+    // instead of 3.4x halo) once there are at least ~3 workgroups per CU of them
+    if (!small && d.k == 3 && d.stride == 1 && tiles_big / 2 >= 768) small = 2;
+    if (const char* e = getenv("JH_CONV3D_TILE")) { if (!small || atoi(e) == 1) small = atoi(e); }
     if (d.k == 1 && d.stride == 1) return conv_launch_3d_k1(a, nr, small, budget, s);
     if (d.k == 2 && d.stride == 2) return conv_launch_3d_k2s2(a, nr, small, budget, s);
     if (d.k == 3 && d.stride <= 2) return conv_launch_3d_k3(a, d.stride, nr, small, budget, s);

@@ -20,6 +20,7 @@
 // sum / sum of squares that the following InstanceNorm needs (fp64 atomics),
 // so no extra pass over the activation is required for the statistics.
 #pragma once
+#include <cstdlib>
 #include "jh_common.h"
 
 namespace jh {
@@ -42,11 +43,80 @@ struct ConvGeom {
   static size_t lds_bytes(int kc) { return (size_t)NPIX * (kc + SPAD) * sizeof(float); }
 };
 
-template <int ND, int K, int STRIDE, int TZ, int TY, int TX, int NR>
+struct EpilogueArgs {
+  float* y;              // output of image n
+  const float* bias;
+  double* stats;         // statistics row of image n, or nullptr
+  int Dout, Hout, Wout, Hy, Wy, cout_p, cout_p16, os, offz, offy, offx;
+};
+
+// Shared epilogue of the MFMA kernels: bias, store of the raw output, and the
+// per-channel sum / sum of squares of the tile (registers -> wave shuffles -> LDS ->
+// one fp64 atomic pair per channel and workgroup).  `red` is >= NW*NR*16*2 floats of LDS
+// (NW = waves per workgroup).
+template <int MR, int NR, int TY, int TX, int NW = 4>
+__device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[MR][NR], const EpilogueArgs& e,
+                                              float* red, int nb0, int oz0, int oy0, int ox0,
+                                              int tid) {
+  const int lane = tid & 63, wave = tid >> 6, mrow = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int nr = 0; nr < NR; ++nr) {
+    const int ch = (nb0 + nr) * 16 + mrow;
+    const bool ch_ok = ch < e.cout_p;
+    const float bv = (e.bias && ch < e.cout_p16) ? e.bias[ch] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int p = (wave * MR + mr) * 16 + kq * 4 + r;
+        const int tx = p % TX, ty = (p / TX) % TY, tz = p / (TX * TY);
+        const int oz = oz0 + tz, oy = oy0 + ty, ox = ox0 + tx;
+        const float v = acc[mr][nr][r] + bv;
+        if (ch_ok && oz < e.Dout && oy < e.Hout && ox < e.Wout) {
+          e.y[((size_t)((oz * e.os + e.offz) * e.Hy + (oy * e.os + e.offy)) * e.Wy + (ox * e.os + e.offx)) * e.cout_p + ch] = v;
+          s1 += v;
+          s2 += v * v;
+        }
+      }
+    }
+    if (e.stats) {
+      s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+      s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+      if (kq == 0) {
+        red[(wave * NR * 16 + nr * 16 + mrow) * 2 + 0] = s1;
+        red[(wave * NR * 16 + nr * 16 + mrow) * 2 + 1] = s2;
+      }
+    }
+  }
+  if (e.stats) {
+    __syncthreads();
+    if (tid < NR * 16) {
+      const int ch = nb0 * 16 + tid;
+      if (ch < e.cout_p) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          s1 += red[(w * NR * 16 + tid) * 2 + 0];
+          s2 += red[(w * NR * 16 + tid) * 2 + 1];
+        }
+        unsafeAtomicAdd(e.stats + (size_t)ch * 2 + 0, (double)s1);
+        unsafeAtomicAdd(e.stats + (size_t)ch * 2 + 1, (double)s2);
+      }
+    }
+  }
+}
+
+template <int ND, int K, int STRIDE, int TZ, int TY, int TX, int NR, int KC8>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   using G = ConvGeom<ND, K, STRIDE, TZ, TY, TX>;
   constexpr int MR = G::MR;
+  constexpr int KC = KC8 * 8;                 // input channels staged per LDS pass
+  constexpr int S = KC + G::SPAD;             // LDS pixel stride in floats (even)
+  constexpr int S2 = S / 2;                   // ... in float2 units
+  constexpr int Q4 = KC / 4;                  // float4 per pixel and pass
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  float2* lds2 = reinterpret_cast<float2*>(lds);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -69,15 +139,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   const int iy0 = oy0 * STRIDE - a.phase[ph].pad[1];
   const int ix0 = ox0 * STRIDE - a.phase[ph].pad[2];
 
-  const int S = a.kc + G::SPAD;   // LDS pixel stride in floats
-
-  // ---- per-lane LDS base of each of this wave's 16-pixel row blocks
+  // ---- per-lane LDS base (float2 units) of each of this wave's 16-pixel row blocks
   int abase[MR];
 #pragma unroll
   for (int mr = 0; mr < MR; ++mr) {
     const int p = (wave * MR + mr) * 16 + mrow;
     const int tx = p % TX, ty = (p / TX) % TY, tz = p / (TX * TY);
-    abase[mr] = (((tz * STRIDE) * G::PY + ty * STRIDE) * G::PX + tx * STRIDE) * S + 2 * kq;
+    abase[mr] = (((tz * STRIDE) * G::PY + ty * STRIDE) * G::PX + tx * STRIDE) * S2 + kq;
   }
 
   f32x4 acc[MR][NR];
@@ -88,187 +156,154 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 
   const float* __restrict__ xin = a.x + (size_t)n * a.Din * a.Hin * a.Win * a.cin_p;
   const int nkc8_total = a.cin_p >> 3;
-  const float* __restrict__ wph = a.w + (size_t)ph * a.phase_stride;
   const int nb16_total = a.cout_p16 >> 4;
+  // per-lane weight base; column blocks past the end are clamped (their results are
+  // never stored), so the main loop has no conditional loads
+  const float2* __restrict__ wlane =
+      reinterpret_cast<const float2*>(a.w + (size_t)ph * a.phase_stride) + lane;
+  int boff[NR];
+#pragma unroll
+  for (int nr = 0; nr < NR; ++nr) boff[nr] = min(nb0 + nr, nb16_total - 1) * 64;
+  const int tap_stride = nkc8_total * nb16_total * 64;     // float2 units
 
-  for (int c0 = 0; c0 < a.cin_p; c0 += a.kc) {
-    const int kcur = min(a.kc, a.cin_p - c0);
-    const int q4 = kcur >> 2;                 // float4 per pixel in this chunk
+  for (int c0 = 0; c0 < a.cin_p; c0 += KC) {
     __syncthreads();
-    // ---- stage the halo patch: [pixel][kcur] with stride S
-    const int total = G::NPIX * q4;
-    for (int idx = tid; idx < total; idx += 256) {
-      const int c4 = idx % q4;
-      const int pix = idx / q4;
+    // ---- stage the halo patch: [pixel][KC] with stride S; channels past cin_p read 0
+    for (int idx = tid; idx < G::NPIX * Q4; idx += 256) {
+      const int c4 = idx % Q4;
+      const int pix = idx / Q4;
       const int px = pix % G::PX;
       const int py = (pix / G::PX) % G::PY;
       const int pz = pix / (G::PX * G::PY);
       const int iz = iz0 + pz, iy = iy0 + py, ix = ix0 + px;
+      const int c = c0 + c4 * 4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (iz >= 0 && iz < a.Din && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) {
+      if (c < a.cin_p && iz >= 0 && iz < a.Din && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) {
         v = *reinterpret_cast<const float4*>(
-            xin + ((size_t)(iz * a.Hin + iy) * a.Win + ix) * a.cin_p + c0 + c4 * 4);
+            xin + ((size_t)(iz * a.Hin + iy) * a.Win + ix) * a.cin_p + c);
         if (a.gate) {
-          const float4 g = *reinterpret_cast<const float4*>(
-              a.gate + (size_t)n * a.cin_p + c0 + c4 * 4);
+          const float4 g = *reinterpret_cast<const float4*>(a.gate + (size_t)n * a.cin_p + c);
           v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w;
         }
       }
-      float2* dst = reinterpret_cast<float2*>(lds + pix * S + c4 * 4);
+      float2* dst = lds2 + pix * S2 + c4 * 2;
       dst[0] = make_float2(v.x, v.y);
       dst[1] = make_float2(v.z, v.w);
     }
     __syncthreads();
 
-    // ---- taps x 8-channel steps, operands prefetched one step ahead
-    const int nk8 = kcur >> 3;
-    const int steps = G::NT * nk8;
-    const int kc8_0 = c0 >> 3;
-    int tap = 0, k8 = 0, dz = 0, dy = 0, dx = 0;
-    float2 an[MR], bn[NR];
-    {
+    // ---- taps: all KC8 8-channel steps of a tap are unrolled; the weights of the
+    // next tap are fetched (L2) while the current tap's MFMAs issue
+    int koff[KC8];
 #pragma unroll
-      for (int mr = 0; mr < MR; ++mr)
-        an[mr] = *reinterpret_cast<const float2*>(lds + abase[mr]);
-      const float* wp = wph + ((size_t)(0 * nkc8_total + kc8_0) * nb16_total + nb0) * 128 + lane * 2;
+    for (int k8 = 0; k8 < KC8; ++k8)
+      koff[k8] = min((c0 >> 3) + k8, nkc8_total - 1) * nb16_total * 64;
+    float2 bn[KC8][NR];
 #pragma unroll
-      for (int nr = 0; nr < NR; ++nr)
-        bn[nr] = (nb0 + nr < nb16_total) ? *reinterpret_cast<const float2*>(wp + nr * 128)
-                                         : make_float2(0.f, 0.f);
-    }
-    for (int it = 0; it < steps; ++it) {
-      float2 ac[MR], bc[NR];
+    for (int k8 = 0; k8 < KC8; ++k8)
 #pragma unroll
-      for (int mr = 0; mr < MR; ++mr) ac[mr] = an[mr];
+      for (int nr = 0; nr < NR; ++nr) bn[k8][nr] = wlane[koff[k8] + boff[nr]];
+    int tap = 0;
+    for (int dz = 0; dz < G::KD; ++dz)
+      for (int dy = 0; dy < G::KH; ++dy) {
+        const int row_off = (dz * G::PY + dy) * G::PX * S2;
 #pragma unroll
-      for (int nr = 0; nr < NR; ++nr) bc[nr] = bn[nr];
-      // advance (tap, k8) and prefetch
-      ++k8;
-      if (k8 == nk8) {
-        k8 = 0; ++tap; ++dx;
-        if (dx == G::KW) { dx = 0; ++dy; if (dy == G::KH) { dy = 0; ++dz; } }
+        for (int dx = 0; dx < G::KW; ++dx, ++tap) {
+          float2 bc[KC8][NR], ac[KC8][MR];
+#pragma unroll
+          for (int k8 = 0; k8 < KC8; ++k8)
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr) ac[k8][mr] = lds2[abase[mr] + row_off + dx * S2 + k8 * 4];
+          const float2* wn = wlane + (size_t)min(tap + 1, G::NT - 1) * tap_stride;
+#pragma unroll
+          for (int k8 = 0; k8 < KC8; ++k8)
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) {
+              bc[k8][nr] = bn[k8][nr];
+              bn[k8][nr] = wn[koff[k8] + boff[nr]];
+            }
+#pragma unroll
+          for (int k8 = 0; k8 < KC8; ++k8) {
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+              for (int nr = 0; nr < NR; ++nr)
+                acc[mr][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[k8][mr].x, bc[k8][nr].x, acc[mr][nr], 0, 0, 0);
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+              for (int nr = 0; nr < NR; ++nr)
+                acc[mr][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[k8][mr].y, bc[k8][nr].y, acc[mr][nr], 0, 0, 0);
+          }
+        }
       }
-      if (it + 1 < steps) {
-        const int toff = ((dz * G::PY + dy) * G::PX + dx) * S + k8 * 8;
-#pragma unroll
-        for (int mr = 0; mr < MR; ++mr)
-          an[mr] = *reinterpret_cast<const float2*>(lds + abase[mr] + toff);
-        const float* wp = wph + ((size_t)(tap * nkc8_total + kc8_0 + k8) * nb16_total + nb0) * 128 + lane * 2;
-#pragma unroll
-        for (int nr = 0; nr < NR; ++nr)
-          bn[nr] = (nb0 + nr < nb16_total) ? *reinterpret_cast<const float2*>(wp + nr * 128)
-                                           : make_float2(0.f, 0.f);
-      }
-#pragma unroll
-      for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-        for (int nr = 0; nr < NR; ++nr)
-          acc[mr][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[mr].x, bc[nr].x, acc[mr][nr], 0, 0, 0);
-#pragma unroll
-      for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-        for (int nr = 0; nr < NR; ++nr)
-          acc[mr][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[mr].y, bc[nr].y, acc[mr][nr], 0, 0, 0);
-    }
   }
 
   // ---- epilogue: bias, store, InstanceNorm statistics
   __syncthreads();                       // LDS is reused for the cross-wave reduce
-  float* red = lds;                      // [4 waves][NR*16][2]
-  const int os = a.ostride;
-  const int offz = a.phase[ph].ooff[0], offy = a.phase[ph].ooff[1], offx = a.phase[ph].ooff[2];
-  float* __restrict__ yout = a.y + (size_t)n * a.Dy * a.Hy * a.Wy * a.cout_p;
-#pragma unroll
-  for (int nr = 0; nr < NR; ++nr) {
-    const int ch = (nb0 + nr) * 16 + mrow;
-    const bool ch_ok = ch < a.cout_p;
-    const float bv = (a.bias && ch < a.cout_p16) ? a.bias[ch] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int mr = 0; mr < MR; ++mr) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int p = (wave * MR + mr) * 16 + kq * 4 + r;
-        const int tx = p % TX, ty = (p / TX) % TY, tz = p / (TX * TY);
-        const int oz = oz0 + tz, oy = oy0 + ty, ox = ox0 + tx;
-        const float v = acc[mr][nr][r] + bv;
-        if (ch_ok && oz < a.Dout && oy < a.Hout && ox < a.Wout) {
-          yout[((size_t)((oz * os + offz) * a.Hy + (oy * os + offy)) * a.Wy + (ox * os + offx)) * a.cout_p + ch] = v;
-          s1 += v;
-          s2 += v * v;
-        }
-      }
-    }
-    if (a.stats) {
-      s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
-      s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-      if (kq == 0) {
-        red[(wave * NR * 16 + nr * 16 + mrow) * 2 + 0] = s1;
-        red[(wave * NR * 16 + nr * 16 + mrow) * 2 + 1] = s2;
-      }
-    }
+  EpilogueArgs e;
+  e.y = a.y + (size_t)n * a.Dy * a.Hy * a.Wy * a.cout_p;
+  e.bias = a.bias;
+  e.stats = a.stats ? a.stats + (size_t)n * a.cout_p * 2 : nullptr;
+  e.Dout = a.Dout; e.Hout = a.Hout; e.Wout = a.Wout; e.Hy = a.Hy; e.Wy = a.Wy;
+  e.cout_p = a.cout_p; e.cout_p16 = a.cout_p16; e.os = a.ostride;
+  e.offz = a.phase[ph].ooff[0]; e.offy = a.phase[ph].ooff[1]; e.offx = a.phase[ph].ooff[2];
+  conv_epilogue<MR, NR, TY, TX>(acc, e, lds, nb0, oz0, oy0, ox0, tid);
+}
+
+// Channels per LDS pass: the candidate (8..32) that wastes the fewest zero-padded
+// channels; ties go to the larger pass (fewer staging rounds).
+inline int pick_kc8(int cin_p, size_t (*lds_bytes)(int), size_t budget) {
+  int best = 1;
+  double best_cost = 1e30;
+  for (int k = 1; k <= 4; ++k) {
+    if (lds_bytes(k * 8) > budget && k > 1) continue;
+    const int chunks = (cin_p + k * 8 - 1) / (k * 8);
+    const double cost = (double)chunks * k * 8 / cin_p + 0.02 * chunks;
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = k; }
   }
-  if (a.stats) {
-    __syncthreads();
-    if (tid < NR * 16) {
-      const int ch = nb0 * 16 + tid;
-      if (ch < a.cout_p) {
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          s1 += red[(w * NR * 16 + tid) * 2 + 0];
-          s2 += red[(w * NR * 16 + tid) * 2 + 1];
-        }
-        double* st = a.stats + ((size_t)n * a.cout_p + ch) * 2;
-        unsafeAtomicAdd(st + 0, (double)s1);
-        unsafeAtomicAdd(st + 1, (double)s2);
-      }
-    }
-  }
+  return best;
 }
 
 // Launch one instantiation.  Returns false if this (nd,k,stride) is not the
 // instantiation's, so callers can chain.
+template <int ND, int K, int STRIDE, int TZ, int TY, int TX, int NRV, int KC8V>
+int launch_conv_inst(const ConvArgs& b, dim3 grid, hipStream_t s) {
+  using G = ConvGeom<ND, K, STRIDE, TZ, TY, TX>;
+  size_t lds = G::lds_bytes(KC8V * 8);
+  const size_t red = (size_t)4 * 4 * 16 * 2 * sizeof(float);
+  if (lds < red) lds = red;
+  JH_REQUIRE(lds <= 160 * 1024, "conv patch does not fit LDS");
+  auto kern = conv_mfma_kernel<ND, K, STRIDE, TZ, TY, TX, NRV, KC8V>;
+  static bool big_lds_enabled = false;
+  if (lds > 64 * 1024 && !big_lds_enabled) {
+    JH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    big_lds_enabled = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, b);
+  JH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 template <int ND, int K, int STRIDE, int TZ, int TY, int TX>
 int launch_conv_geom(const ConvArgs& a, int nr, size_t lds_budget, hipStream_t s) {
   using G = ConvGeom<ND, K, STRIDE, TZ, TY, TX>;
   ConvArgs b = a;
-  // largest channel chunk (multiple of 8) whose patch fits the LDS budget
-  int kc = b.cin_p;
-  while (kc > 8 && G::lds_bytes(kc) > lds_budget) kc -= 8;
-  const int nchunk = (b.cin_p + kc - 1) / kc;         // balance the chunks
-  kc = round_up((b.cin_p + nchunk - 1) / nchunk, 8);
-  b.kc = kc;
-  size_t lds = G::lds_bytes(kc);
-  const size_t red = (size_t)4 * 4 * 16 * 2 * sizeof(float);
-  if (lds < red) lds = red;
-  JH_REQUIRE(lds <= 160 * 1024, "conv patch does not fit LDS");
+  if (const char* e = getenv("JH_CONV_LDS_KB")) lds_budget = (size_t)atoi(e) * 1024;
+  int kc8 = pick_kc8(b.cin_p, &G::lds_bytes, lds_budget);
+  if (const char* e = getenv("JH_CONV_KC8")) kc8 = atoi(e);
+  b.kc = kc8 * 8;
   const int tiles = ((b.Dout + TZ - 1) / TZ) * ((b.Hout + TY - 1) / TY) * ((b.Wout + TX - 1) / TX);
   const int nb = b.cout_p16 / 16;
   dim3 grid(tiles, (nb + nr - 1) / nr, b.N * b.nphase);
-  dim3 block(256);
-#define JH_CONV_LAUNCH(NRV)                                                                   \
-  case NRV: {                                                                                 \
-    auto kern = conv_mfma_kernel<ND, K, STRIDE, TZ, TY, TX, NRV>;                            \
-    static bool big_lds_enabled = false;                                                      \
-    if (lds > 64 * 1024 && !big_lds_enabled) {                                                \
-      JH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                   \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-      big_lds_enabled = true;                                                                 \
-    }                                                                                         \
-    hipLaunchKernelGGL(kern, grid, block, lds, s, b);                                         \
-  } break;
-  switch (nr) {
-    JH_CONV_LAUNCH(1)
-    JH_CONV_LAUNCH(2)
-    JH_CONV_LAUNCH(3)
-    JH_CONV_LAUNCH(4)
-    default:
-      JH_REQUIRE(false, "bad NR");
-  }
-#undef JH_CONV_LAUNCH
-  JH_CHECK_HIP(hipGetLastError());
-  return 0;
+#define JH_CONV_CASE(NRV, KV) \
+  if (nr == NRV && kc8 == KV) return launch_conv_inst<ND, K, STRIDE, TZ, TY, TX, NRV, KV>(b, grid, s);
+#define JH_CONV_ROW(NRV) JH_CONV_CASE(NRV, 1) JH_CONV_CASE(NRV, 2) JH_CONV_CASE(NRV, 3) JH_CONV_CASE(NRV, 4)
+  JH_CONV_ROW(1) JH_CONV_ROW(2) JH_CONV_ROW(3) JH_CONV_ROW(4)
+#undef JH_CONV_ROW
+#undef JH_CONV_CASE
+  JH_REQUIRE(false, "bad (NR, KC8)");
 }
 
 // per-translation-unit entry points (one .hip file per kernel family so the

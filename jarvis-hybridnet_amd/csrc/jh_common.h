@@ -147,6 +147,10 @@ struct FuseArgs {
 int launch_fuse(const FuseArgs& f, const Act& out, hipStream_t s);
 int launch_maxpool2(const Act& x, float* y, hipStream_t s);
 
+// fused BiFPN node (csrc/bifpn_node.hip)
+struct NodeArgs;
+int launch_bifpn_node(const NodeArgs& a, hipStream_t s);
+
 // ---------------------------------------------------------------- layout moves
 // NCHW/NCDHW fp32 -> channel-last padded (pad channels zeroed) and back.
 int launch_to_channel_last(const float* src, const Act& dst, hipStream_t s);

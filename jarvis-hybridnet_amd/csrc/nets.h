@@ -73,6 +73,14 @@ class Plan {
                 float* y, long pool_off);
 };
 
+// A tensor as consumers see it: the raw conv output plus the statistics the
+// InstanceNorm that follows it needs (st < 0: already normalised / no norm).
+struct Ref {
+  Act a;
+  long st = -1;
+  float inv = 0.f;       // 1 / pixels the statistics were accumulated over
+};
+
 class EffTrackPlan : public Plan {
  public:
   // size: 0 small, 1 medium, 2 large.  N images of H x W (multiples of 64).
@@ -84,10 +92,10 @@ class EffTrackPlan : public Plan {
  private:
   int mbconv(const ParamMap& pm, const std::string& p, int stage, int k, int stride, int cin,
              int cout, int expand, const Act& x, Act* out);
-  int sepconv(const ParamMap& pm, const std::string& p, int cout, const Act& x, Act* out);
-  int lateral(const ParamMap& pm, const std::string& p, int cout, const Act& x, Act* out);
-  int fuse(int n_in, const Act* ins, const int* modes, const float* w, int act, const Act& like,
-           Act* out);
+  int lateral(const ParamMap& pm, const std::string& p, int cout, const Act& x, Ref* out);
+  int pool(const Ref& x, Ref* out);
+  int node(const ParamMap& pm, const std::string& conv_prefix, int n_in, const Ref* ins,
+           const int* modes, const float* w, int act, const Act& like, int cout, Ref* out);
 };
 
 class V2VPlan : public Plan {

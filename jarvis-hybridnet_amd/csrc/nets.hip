@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstring>
 #include "nets.h"
+#include "bifpn_node.h"
 
 namespace jh {
 
@@ -242,49 +243,79 @@ int EffTrackPlan::mbconv(const ParamMap& pm, const std::string& p, int stage, in
   return 0;
 }
 
-// SeparableConvBlock.forward, model.py:223-232 (norm=True, activation=False
-// everywhere it is used on this path, including first_conv)
-int EffTrackPlan::sepconv(const ParamMap& pm, const std::string& p, int cout, const Act& x,
-                          Act* out) {
-  const float* w = nullptr;
-  if (get(pm, p + "depthwise_conv.weight", (size_t)x.C * 9, &w)) return 1;
-  std::vector<float> wt((size_t)9 * x.Cp, 0.f);
-  for (int c = 0; c < x.C; ++c)
-    for (int t = 0; t < 9; ++t) wt[(size_t)t * x.Cp + c] = w[(size_t)c * 9 + t];
-  float* wd = nullptr;
-  if (upload(wt, &wd)) return 1;
-  Act dw;
-  if (new_act(x.N, 1, x.H, x.W, x.C, &dw)) return 1;
-  push("depthwise_k3", 18.0 * x.N * x.pixels() * x.C, 8.0 * x.N * x.pixels() * x.C,
-       [x, wd, dw](hipStream_t s) { return launch_depthwise(x, wd, 3, dw.p, nullptr, s); });
-  if (new_act(x.N, 1, x.H, x.W, cout, out)) return 1;
-  size_t st = 0;
-  if (add_conv(pm, conv_desc(2, 1, 1, 0, x.C, cout), p + "pointwise_conv.weight",
-               p + "pointwise_conv.bias", false, dw, *out, nullptr, true, &st)) return 1;
-  add_norm(*out, st, ACT_NONE, nullptr, nullptr, out->p, -1);
-  return 0;
-}
-
-// 1x1 conv + bias + InstanceNorm (model.py:404-425)
+// 1x1 conv + bias; its InstanceNorm (model.py:404-425) is applied by the consumers
+// from the fused statistics
 int EffTrackPlan::lateral(const ParamMap& pm, const std::string& p, int cout, const Act& x,
-                          Act* out) {
-  if (new_act(x.N, 1, x.H, x.W, cout, out)) return 1;
+                          Ref* out) {
+  if (new_act(x.N, 1, x.H, x.W, cout, &out->a)) return 1;
   size_t st = 0;
   if (add_conv(pm, conv_desc(2, 1, 1, 0, x.C, cout), p + ".0.weight", p + ".0.bias", false, x,
-               *out, nullptr, true, &st)) return 1;
-  add_norm(*out, st, ACT_NONE, nullptr, nullptr, out->p, -1);
+               out->a, nullptr, true, &st)) return 1;
+  out->st = (long)st;
+  out->inv = 1.f / (float)(x.H * x.W);
   return 0;
 }
 
-int EffTrackPlan::fuse(int n_in, const Act* ins, const int* modes, const float* w, int act,
-                       const Act& like, Act* out) {
-  if (new_act(like.N, 1, like.H, like.W, like.C, out)) return 1;
-  FuseArgs f{};
-  f.n_in = n_in; f.act = act;
-  for (int i = 0; i < n_in; ++i) { f.in[i] = ins[i].p; f.mode[i] = modes[i]; f.w[i] = w[i]; }
-  const Act o = *out;
-  push("bifpn_fuse", 2.0 * n_in * o.N * o.pixels() * o.C, 4.0 * (n_in + 1) * o.N * o.pixels() * o.C,
-       [f, o](hipStream_t s) { return launch_fuse(f, o, s); });
+// MaxPool2d(2,2) of a not-yet-normalised tensor: max commutes with the (monotone)
+// InstanceNorm map, so the pooled raw tensor keeps the producer's statistics.
+int EffTrackPlan::pool(const Ref& x, Ref* out) {
+  if (new_act(x.a.N, 1, x.a.H / 2, x.a.W / 2, x.a.C, &out->a)) return 1;
+  out->st = x.st;
+  out->inv = x.inv;
+  const Act a = x.a, o = out->a;
+  push("maxpool2", 0, 5.0 * o.N * o.pixels() * o.C * 4,
+       [a, o](hipStream_t s) { return launch_maxpool2(a, o.p, s); });
+  return 0;
+}
+
+// One fused BiFPN node (csrc/bifpn_node.hip): weighted fusion of normalised inputs
+// + activation + SeparableConvBlock (depthwise 3x3, pointwise 1x1 + bias); the
+// block's InstanceNorm is again left to the consumers.
+int EffTrackPlan::node(const ParamMap& pm, const std::string& cp, int n_in, const Ref* ins,
+                       const int* modes, const float* w, int act, const Act& like, int cout,
+                       Ref* out) {
+  const int cin = like.C;
+  const float* dwh = nullptr;
+  if (get(pm, cp + "depthwise_conv.weight", (size_t)cin * 9, &dwh)) return 1;
+  std::vector<float> wt((size_t)9 * like.Cp, 0.f);
+  for (int c = 0; c < cin; ++c)
+    for (int t = 0; t < 9; ++t) wt[(size_t)t * like.Cp + c] = dwh[(size_t)c * 9 + t];
+  float* dwd = nullptr;
+  if (upload(wt, &dwd)) return 1;
+  const float *pwh = nullptr, *bh = nullptr;
+  if (get(pm, cp + "pointwise_conv.weight", (size_t)cin * cout, &pwh)) return 1;
+  if (get(pm, cp + "pointwise_conv.bias", cout, &bh)) return 1;
+  ConvWeights cw;
+  if (pack_conv_weights(conv_desc(2, 1, 1, 0, cin, cout), pwh, bh, false, &cw)) return 1;
+  convs_.push_back(cw);
+  if (new_act(like.N, 1, like.H, like.W, cout, &out->a)) return 1;
+  const size_t st = scratch((size_t)like.N * out->a.Cp * 2);
+  out->st = (long)st;
+  out->inv = 1.f / (float)(like.H * like.W);
+  NodeArgs a{};
+  a.n_in = n_in; a.act = act;
+  long sts[3] = {-1, -1, -1};
+  double bytes = 4.0 * like.N * like.pixels() * cout;
+  for (int i = 0; i < n_in; ++i) {
+    a.in[i] = ins[i].a.p; a.mode[i] = modes[i]; a.w[i] = w[i]; a.inv_cnt[i] = ins[i].inv;
+    sts[i] = ins[i].st;
+    bytes += 4.0 * ins[i].a.N * ins[i].a.pixels() * cin;
+  }
+  a.dw = dwd; a.pw = cw.w; a.bias = cw.bias; a.y = out->a.p;
+  a.N = like.N; a.H = like.H; a.W = like.W; a.Cp = like.Cp;
+  a.cout_p = out->a.Cp; a.cout_p16 = cw.cout_p16;
+  const double px = (double)like.N * like.pixels();
+  char nm[64];
+  snprintf(nm, sizeof nm, "bifpn_node_%dx%d@%d", cin, cout, like.W);
+  const long s0 = sts[0], s1 = sts[1], s2 = sts[2];
+  push(nm, 2.0 * px * cin * (9.0 + cout), bytes, [this, a, s0, s1, s2, st](hipStream_t s) {
+    NodeArgs b = a;
+    b.st[0] = s0 >= 0 ? sc((size_t)s0) : nullptr;
+    b.st[1] = s1 >= 0 ? sc((size_t)s1) : nullptr;
+    b.st[2] = s2 >= 0 ? sc((size_t)s2) : nullptr;
+    b.stats = sc(st);
+    return launch_bifpn_node(b, s);
+  });
   return 0;
 }
 
@@ -321,19 +352,18 @@ int EffTrackPlan::build(const ParamMap& pm, const std::string& pre, int size, in
   }
   JH_REQUIRE(nf == 3, "feature taps");
 
-  // BiFPN cells (model.py:301-353, 446-504)
+  // BiFPN cells (model.py:301-353, 446-504).  Every tensor inside the pyramid is
+  // kept as "raw conv output + statistics"; the fused node kernel normalises on load.
   const int Wf = ss.fpn;
-  Act p3, p4, p5, p6, p7;
+  Ref p3, p4, p5, p6, p7;
   for (int cell = 0; cell < ss.cells; ++cell) {
     const std::string p = pre + "bifpn." + std::to_string(cell) + ".";
-    Act p3_in, p4_in, p5_in, p6_in, p7_in, p4_in2, p5_in2;
+    Ref p3_in, p4_in, p5_in, p6_in, p7_in, p4_in2, p5_in2;
     if (cell == 0) {
-      Act t6;
+      Ref t6;
       if (lateral(pm, p + "p5_to_p6", Wf, feats[2], &t6)) return 1;
-      if (new_act(N, 1, t6.H / 2, t6.W / 2, Wf, &p6_in)) return 1;
-      { const Act a = t6, o = p6_in; push("maxpool2", 0, 5.0 * o.N * o.pixels() * o.C * 4, [a, o](hipStream_t s) { return launch_maxpool2(a, o.p, s); }); }
-      if (new_act(N, 1, p6_in.H / 2, p6_in.W / 2, Wf, &p7_in)) return 1;
-      { const Act a = p6_in, o = p7_in; push("maxpool2", 0, 5.0 * o.N * o.pixels() * o.C * 4, [a, o](hipStream_t s) { return launch_maxpool2(a, o.p, s); }); }
+      if (pool(t6, &p6_in)) return 1;
+      if (pool(p6_in, &p7_in)) return 1;
       if (lateral(pm, p + "p3_down_channel", Wf, feats[0], &p3_in)) return 1;
       if (lateral(pm, p + "p4_down_channel", Wf, feats[1], &p4_in)) return 1;
       if (lateral(pm, p + "p5_down_channel", Wf, feats[2], &p5_in)) return 1;
@@ -343,44 +373,43 @@ int EffTrackPlan::build(const ParamMap& pm, const std::string& pre, int size, in
       p3_in = p3; p4_in = p4; p5_in = p5; p6_in = p6; p7_in = p7;
       p4_in2 = p4; p5_in2 = p5;
     }
-    auto node = [&](const char* wname, int n_in, const Act* ins, const int* modes, const Act& like,
-                    const char* conv, Act* out) -> int {
+    auto fnode = [&](const char* wname, int n_in, const Ref* ins, const int* modes, const Ref& like,
+                     const char* conv, Ref* out) -> int {
       const float* wp = nullptr;
       if (get(pm, p + wname, n_in, &wp)) return 1;
       float w[3];
       fuse_weights(wp, n_in, w);
-      Act f;
-      if (fuse(n_in, ins, modes, w, ACT_SILU, like, &f)) return 1;
-      return sepconv(pm, p + conv + ".", Wf, f, out);
+      return node(pm, p + conv + ".", n_in, ins, modes, w, ACT_SILU, like.a, Wf, out);
     };
     const int m_up[2] = {FUSE_SAME, FUSE_UP2};
     const int m_dn3[3] = {FUSE_SAME, FUSE_SAME, FUSE_POOL2};
     const int m_dn2[2] = {FUSE_SAME, FUSE_POOL2};
-    Act p6_up, p5_up, p4_up, p3_out, p4_out, p5_out, p6_out, p7_out;
-    { const Act in[2] = {p6_in, p7_in}; if (node("p6_w1", 2, in, m_up, p6_in, "conv6_up", &p6_up)) return 1; }
-    { const Act in[2] = {p5_in, p6_up}; if (node("p5_w1", 2, in, m_up, p5_in, "conv5_up", &p5_up)) return 1; }
-    { const Act in[2] = {p4_in, p5_up}; if (node("p4_w1", 2, in, m_up, p4_in, "conv4_up", &p4_up)) return 1; }
-    { const Act in[2] = {p3_in, p4_up}; if (node("p3_w1", 2, in, m_up, p3_in, "conv3_up", &p3_out)) return 1; }
-    { const Act in[3] = {p4_in2, p4_up, p3_out}; if (node("p4_w2", 3, in, m_dn3, p4_in2, "conv4_down", &p4_out)) return 1; }
-    { const Act in[3] = {p5_in2, p5_up, p4_out}; if (node("p5_w2", 3, in, m_dn3, p5_in2, "conv5_down", &p5_out)) return 1; }
-    { const Act in[3] = {p6_in, p6_up, p5_out}; if (node("p6_w2", 3, in, m_dn3, p6_in, "conv6_down", &p6_out)) return 1; }
-    { const Act in[2] = {p7_in, p6_out}; if (node("p7_w2", 2, in, m_dn2, p7_in, "conv7_down", &p7_out)) return 1; }
+    Ref p6_up, p5_up, p4_up, p3_out, p4_out, p5_out, p6_out, p7_out;
+    { const Ref in[2] = {p6_in, p7_in}; if (fnode("p6_w1", 2, in, m_up, p6_in, "conv6_up", &p6_up)) return 1; }
+    { const Ref in[2] = {p5_in, p6_up}; if (fnode("p5_w1", 2, in, m_up, p5_in, "conv5_up", &p5_up)) return 1; }
+    { const Ref in[2] = {p4_in, p5_up}; if (fnode("p4_w1", 2, in, m_up, p4_in, "conv4_up", &p4_up)) return 1; }
+    { const Ref in[2] = {p3_in, p4_up}; if (fnode("p3_w1", 2, in, m_up, p3_in, "conv3_up", &p3_out)) return 1; }
+    { const Ref in[3] = {p4_in2, p4_up, p3_out}; if (fnode("p4_w2", 3, in, m_dn3, p4_in2, "conv4_down", &p4_out)) return 1; }
+    { const Ref in[3] = {p5_in2, p5_up, p4_out}; if (fnode("p5_w2", 3, in, m_dn3, p5_in2, "conv5_down", &p5_out)) return 1; }
+    { const Ref in[3] = {p6_in, p6_up, p5_out}; if (fnode("p6_w2", 3, in, m_dn3, p6_in, "conv6_down", &p6_out)) return 1; }
+    { const Ref in[2] = {p7_in, p6_out}; if (fnode("p7_w2", 2, in, m_dn2, p7_in, "conv7_down", &p7_out)) return 1; }
     p3 = p3_out; p4 = p4_out; p5 = p5_out; p6 = p6_out; p7 = p7_out;
   }
 
-  // head: softplus-normalised 3-way fusion, first_conv, deconv1 (model.py:119-127)
+  // head: softplus-normalised 3-way fusion + first_conv as one fused node, its
+  // InstanceNorm materialised for deconv1 (model.py:119-127)
   const float* wc = nullptr;
   if (get(pm, pre + "weights_cat", 3, &wc)) return 1;
   float w[3], sum = 0.f;
   for (int i = 0; i < 3; ++i) { w[i] = wc[i] > 20.f ? wc[i] : log1pf(expf(wc[i])); sum += w[i]; }
   for (int i = 0; i < 3; ++i) w[i] = w[i] / (sum + 0.0001f);
-  const Act hin[3] = {p3, p4, p5};
+  const Ref hin[3] = {p3, p4, p5};
   const int hmodes[3] = {FUSE_SAME, FUSE_UP2, FUSE_UP4};
-  Act x1, mid;
-  if (fuse(3, hin, hmodes, w, ACT_NONE, p3, &x1)) return 1;
-  if (sepconv(pm, pre + "first_conv.", ss.head, x1, &mid)) return 1;
-  if (new_act(N, 1, mid.H * 2, mid.W * 2, J, &heat)) return 1;
-  if (add_conv(pm, deconv2d_k4s2p1_desc(ss.head, J), pre + "deconv1.weight", "", true, mid, heat,
+  Ref mid;
+  if (node(pm, pre + "first_conv.", 3, hin, hmodes, w, ACT_NONE, p3.a, ss.head, &mid)) return 1;
+  add_norm(mid.a, (size_t)mid.st, ACT_NONE, nullptr, nullptr, mid.a.p, -1);
+  if (new_act(N, 1, mid.a.H * 2, mid.a.W * 2, J, &heat)) return 1;
+  if (add_conv(pm, deconv2d_k4s2p1_desc(ss.head, J), pre + "deconv1.weight", "", true, mid.a, heat,
                nullptr, false, nullptr)) return 1;
   return finish();
 }

@@ -88,3 +88,56 @@ def test_predictor3d_time_batch():
         if p is not None:
             assert (pts[t] - p[0]).abs().max().item() < 1e-4
             assert (conf[t] - q[0]).abs().max().item() < 1e-6
+
+
+def test_sharded_stages_emulated_two_ranks():
+    """The camera-sharded stage API on ONE GPU: two NativePredictors own half of
+    the cameras each, the two exchanges of distributed.py are done by hand
+    (concatenation = what the collectives deliver).  Result must equal the
+    single-predictor forward bit-for-bit (sharding only moves data; InstanceNorm
+    is per image, so per-camera batching is order independent)."""
+    from jarvis_hybridnet_amd import synthetic as S
+    from jarvis_hybridnet_amd._predictor import NativePredictor
+    c = cases.PREDICTOR_CASES["cfg2"]
+    inp = cases.predictor_inputs("cfg2")
+    calib = (inp["cam"], inp["intr"], inp["dist"])
+    T, C, J, world = 2, c["C"], c["J"], 2
+    frames = cuda(torch.stack([inp["imgs"], S.blob_frames(calib, c["W"], c["H"], J, 60)[0]]))
+    common = dict(num_cameras=C, num_joints=J, center_size=c["center_size"], bbox=c["bbox"],
+                  roi_cube_size=c["roi"], grid_spacing=c["spacing"], img_h=c["H"], img_w=c["W"],
+                  mean=S.MEAN, std=S.STD, time_batch=T)
+    dev = [cuda(t) for t in calib]
+    full = NativePredictor(inp["sd_center"], inp["sd_hybrid"], **common)
+    full.set_calibration(*dev)
+    rp, rc, rv = [t.clone() for t in full.forward(frames)]
+    Cl, T3 = C // world, T // world
+    ranks = []
+    for r in range(world):
+        p = NativePredictor(inp["sd_center"], inp["sd_hybrid"], time_batch_3d=T3, cam_lo=r * Cl,
+                            cam_n=Cl, **common)
+        p.set_calibration(*dev)
+        ranks.append(p)
+    local = [frames[:, r * Cl:(r + 1) * Cl].contiguous() for r in range(world)]
+    dets = []
+    for r, p in enumerate(ranks):
+        d = torch.empty((T, Cl, 3), device="cuda")
+        p.stage_center(local[r], d)
+        dets.append(d)
+    det_all = torch.cat(dets, 1).contiguous()                       # exchange 1
+    heats = []
+    for r, p in enumerate(ranks):
+        h = torch.empty((T, Cl, p.Hh, p.Hh, p.Jp), device="cuda")
+        p.stage_keypoints(local[r], det_all, h)
+        heats.append(h)
+    heat_all = torch.cat(heats, 1).contiguous()                     # exchange 2
+    for r, p in enumerate(ranks):
+        pts = torch.empty((T3, J, 3), device="cuda")
+        conf = torch.empty((T3, J), device="cuda")
+        valid = torch.empty((T3,), device="cuda", dtype=torch.int32)
+        p.stage_3d(heat_all[r * T3:(r + 1) * T3].contiguous(), r * T3, pts, conf, valid)
+        torch.cuda.synchronize()
+        assert torch.equal(valid, rv[r * T3:(r + 1) * T3])
+        ep = (pts - rp[r * T3:(r + 1) * T3]).abs().max().item()
+        ec = (conf - rc[r * T3:(r + 1) * T3]).abs().max().item()
+        report("sharded_emulated", rank=r, points_mm=ep, conf=ec)
+        assert ep < 1e-4 and ec < 1e-6
