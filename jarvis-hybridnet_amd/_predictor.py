@@ -33,7 +33,7 @@ class NativePredictor:
         self.device_bytes = N.lib().jh_predictor_device_bytes(self.handle)
 
     def close(self):
-        if getattr(self, "handle", None):
+        if getattr(self, "handle", None) and N is not None and N._lib is not None:
             N.lib().jh_predictor_destroy(self.handle)
             self.handle = None
 

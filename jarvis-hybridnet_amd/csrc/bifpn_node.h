@@ -16,7 +16,8 @@ struct NodeArgs {
   const float* bias;       // [cout_p16]
   float* y;                // raw output [N][H][W][cout_p]
   double* stats;           // [N][cout_p][2]
-  int N, H, W, Cp, cout_p, cout_p16, cf;   // cf = channels per halo chunk (multiple of 4)
+  int N, H, W, Cp, cout_p, cout_p16, cf;
+  int abl = 0;             // ablation bits for timing experiments (0 in production)   // cf = channels per halo chunk (multiple of 4)
 };
 
 

@@ -11,9 +11,7 @@
 // expression :119-126.  Unfused this was fuse + depthwise + pointwise + norm_apply =
 // 9 passes over a P3-sized tensor; fused it is (n_in reads + 1 write).
 //
-// Tile: 8 x 16 output pixels per workgroup of 512 threads (8 waves x 1 row block of
-// 16 pixels; 8 waves because the prologue is latency-bound and LDS limits the CU to
-// 3 workgroups).
+// Tile: 8 x 16 output pixels per workgroup (4 waves x 2 row blocks of 16 pixels).
 //   1. mean / rstd of every normalised input -> LDS
 //   2. per channel chunk: fused + activated halo tile (10 x 18 pixels) -> LDS F,
 //      depthwise 3x3 from F -> LDS operand tile A[128][Cp + 4]
@@ -61,9 +59,9 @@ __device__ __forceinline__ float node_act(float v, int act) {
 template <int NIN, int M0, int M1, int M2>
 __global__ __launch_bounds__(512) void bifpn_node_kernel(const NodeArgs a) {
   constexpr int kModes[3] = {M0, M1, M2};
-  constexpr int U = 2;                           // items in flight per thread
-  constexpr int NT = 512;                        // threads
-  constexpr int KPRE = 8;                        // 8-channel steps whose weights are preloaded
+  constexpr int U = 5;                           // items in flight per thread: 512 x 5 covers a
+                                                 // whole 56-channel halo tile in one round trip
+  constexpr int NT = 512;                        // threads (8 waves: latency-bound prologue)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int Cp = a.Cp;
   const int SA = Cp + 4;                         // operand tile stride (floats)
@@ -79,19 +77,8 @@ __global__ __launch_bounds__(512) void bifpn_node_kernel(const NodeArgs a) {
   const int n = blockIdx.y;
   const int oy0 = tile_y * kNodeTY, ox0 = tile_x * kNodeTX;
 
-  // 0. pointwise weights of the first column-block group: issued now, consumed in
-  // step 3, so their L2 latency hides behind the whole prologue
   const int nk8 = Cp >> 3, nb = a.cout_p16 >> 4;
   const float2* wl = reinterpret_cast<const float2*>(a.pw) + lane;
-  float2 bpre[KPRE][kNodeNRG];
-  const bool pre = nk8 <= KPRE;
-  if (pre) {
-#pragma unroll
-    for (int k8 = 0; k8 < KPRE; ++k8)
-#pragma unroll
-      for (int nr = 0; nr < kNodeNRG; ++nr)
-        bpre[k8][nr] = wl[(size_t)min(k8, nk8 - 1) * nb * 64 + min(nr, nb - 1) * 64];
-  }
   for (int i = tid; i < 9 * Cp; i += NT) dwl[i] = a.dw[i];
 
   // 1. statistics -> mean / rstd (biased variance, eps 1e-5) of every normalised input
@@ -153,14 +140,16 @@ __global__ __launch_bounds__(512) void bifpn_node_kernel(const NodeArgs a) {
               r.z = __fadd_rn(r.z, __fmul_rn(wk, x.z)); r.w = __fadd_rn(r.w, __fmul_rn(wk, x.w));
             }
           }
-          r.x = node_act(r.x, a.act); r.y = node_act(r.y, a.act);
-          r.z = node_act(r.z, a.act); r.w = node_act(r.w, a.act);
+          if (!(a.abl & 1)) {
+            r.x = node_act(r.x, a.act); r.y = node_act(r.y, a.act);
+            r.z = node_act(r.z, a.act); r.w = node_act(r.w, a.act);
+          }
         }
         *reinterpret_cast<float4*>(Ft + pix * SF + c4 * 4) = r;
       }
     }
     __syncthreads();
-    for (int idx = tid; idx < 128 * q; idx += NT) {
+    for (int idx = tid; idx < ((a.abl & 2) ? 0 : 128 * q); idx += NT) {
       const int c4 = idx % q, p = idx / q;
       const int tx = p % kNodeTX, ty = p / kNodeTX;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -178,7 +167,8 @@ __global__ __launch_bounds__(512) void bifpn_node_kernel(const NodeArgs a) {
     __syncthreads();
   }
 
-  // 3. pointwise convolution on the matrix cores: wave w owns pixel rows 16w .. 16w+15
+  // 3. pointwise convolution on the matrix cores: wave w owns pixels 16w .. 16w+15
+  if (a.abl & 4) return;
   const float2* A2 = reinterpret_cast<const float2*>(At);
   const int SA2 = SA >> 1;
   const int abase = (wave * 16 + mrow) * SA2 + kq;
@@ -192,42 +182,30 @@ __global__ __launch_bounds__(512) void bifpn_node_kernel(const NodeArgs a) {
     f32x4 acc[1][kNodeNRG];
 #pragma unroll
     for (int nr = 0; nr < kNodeNRG; ++nr) acc[0][nr] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (pre && nb0 == 0) {
+    int boff[kNodeNRG];
 #pragma unroll
-      for (int k8 = 0; k8 < KPRE; ++k8) {
-        if (k8 < nk8) {
-          const float2 ac = A2[abase + k8 * 4];
+    for (int nr = 0; nr < kNodeNRG; ++nr) boff[nr] = min(nb0 + nr, nb - 1) * 64;
+    float2 bn[kNodeNRG], bnn[kNodeNRG];
 #pragma unroll
-          for (int nr = 0; nr < kNodeNRG; ++nr)
-            acc[0][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac.x, bpre[k8][nr].x, acc[0][nr], 0, 0, 0);
+    for (int nr = 0; nr < kNodeNRG; ++nr) {
+      bn[nr] = wl[boff[nr]];
+      bnn[nr] = wl[(size_t)min(1, nk8 - 1) * nb * 64 + boff[nr]];
+    }
+    for (int k8 = 0; k8 < nk8; ++k8) {
+      float2 bc[kNodeNRG];
+      const float2 ac = A2[abase + k8 * 4];
+      const float2* wn = wl + (size_t)min(k8 + 2, nk8 - 1) * nb * 64;
 #pragma unroll
-          for (int nr = 0; nr < kNodeNRG; ++nr)
-            acc[0][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac.y, bpre[k8][nr].y, acc[0][nr], 0, 0, 0);
-        }
-      }
-    } else {
-      int boff[kNodeNRG];
+      for (int nr = 0; nr < kNodeNRG; ++nr) { bc[nr] = bn[nr]; bn[nr] = bnn[nr]; bnn[nr] = wn[boff[nr]]; }
 #pragma unroll
-      for (int nr = 0; nr < kNodeNRG; ++nr) boff[nr] = min(nb0 + nr, nb - 1) * 64;
-      float2 bn[kNodeNRG];
+      for (int nr = 0; nr < kNodeNRG; ++nr)
+        acc[0][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac.x, bc[nr].x, acc[0][nr], 0, 0, 0);
 #pragma unroll
-      for (int nr = 0; nr < kNodeNRG; ++nr) bn[nr] = wl[boff[nr]];
-      for (int k8 = 0; k8 < nk8; ++k8) {
-        float2 bc[kNodeNRG];
-        const float2 ac = A2[abase + k8 * 4];
-        const float2* wn = wl + (size_t)min(k8 + 1, nk8 - 1) * nb * 64;
-#pragma unroll
-        for (int nr = 0; nr < kNodeNRG; ++nr) { bc[nr] = bn[nr]; bn[nr] = wn[boff[nr]]; }
-#pragma unroll
-        for (int nr = 0; nr < kNodeNRG; ++nr)
-          acc[0][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac.x, bc[nr].x, acc[0][nr], 0, 0, 0);
-#pragma unroll
-        for (int nr = 0; nr < kNodeNRG; ++nr)
-          acc[0][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac.y, bc[nr].y, acc[0][nr], 0, 0, 0);
-      }
+      for (int nr = 0; nr < kNodeNRG; ++nr)
+        acc[0][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac.y, bc[nr].y, acc[0][nr], 0, 0, 0);
     }
     __syncthreads();          // Ft is reused as the reduction scratch of the epilogue
-    conv_epilogue<1, kNodeNRG, kNodeTY, kNodeTX, 8>(acc, e, Ft, nb0, 0, oy0, ox0, tid);
+    if (!(a.abl & 8)) conv_epilogue<1, kNodeNRG, kNodeTY, kNodeTX, 8>(acc, e, Ft, nb0, 0, oy0, ox0, tid);
     __syncthreads();
   }
 }
@@ -249,10 +227,11 @@ static int launch_node_variant(const NodeArgs& a, size_t lds, hipStream_t s) {
 
 int launch_bifpn_node(const NodeArgs& args, hipStream_t s) {
   NodeArgs a = args;
+  if (const char* e = getenv("JH_NODE_ABL")) a.abl = atoi(e);   // timing experiments only
   // halo chunk: as many channels as keep the whole workgroup under the LDS budget
   // (3 workgroups per CU for the 56-channel pyramid of the small model)
   const size_t fixed = ((size_t)3 * a.Cp * 2 + (size_t)9 * a.Cp + (size_t)128 * (a.Cp + 4)) * sizeof(float);
-  size_t budget = 52 * 1024;
+  size_t budget = 78 * 1024;
   if (const char* e = getenv("JH_NODE_LDS_KB")) budget = (size_t)atoi(e) * 1024;
   if (fixed + (size_t)kNodePY * kNodePX * 12 * sizeof(float) > budget) budget = 78 * 1024;
   if (fixed + (size_t)kNodePY * kNodePX * 12 * sizeof(float) > budget) budget = 156 * 1024;

@@ -54,11 +54,20 @@ struct EpilogueArgs {
 // per-channel sum / sum of squares of the tile (registers -> wave shuffles -> LDS ->
 // one fp64 atomic pair per channel and workgroup).  `red` is >= NW*NR*16*2 floats of LDS
 // (NW = waves per workgroup).
+// exchange with the lane whose index differs in bit 0 / bit 1 (DPP quad permutes)
+__device__ __forceinline__ float quad_xor1(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_xor2(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
+}
+
 template <int MR, int NR, int TY, int TX, int NW = 4>
 __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[MR][NR], const EpilogueArgs& e,
                                               float* red, int nb0, int oz0, int oy0, int ox0,
                                               int tid) {
   const int lane = tid & 63, wave = tid >> 6, mrow = lane & 15, kq = lane >> 4;
+  const int j = lane & 3;                  // position inside the lane quad
 #pragma unroll
   for (int nr = 0; nr < NR; ++nr) {
     const int ch = (nb0 + nr) * 16 + mrow;
@@ -67,18 +76,35 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[MR][NR], const Epilog
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) {
+      float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int p = (wave * MR + mr) * 16 + kq * 4 + r;
         const int tx = p % TX, ty = (p / TX) % TY, tz = p / (TX * TY);
-        const int oz = oz0 + tz, oy = oy0 + ty, ox = ox0 + tx;
-        const float v = acc[mr][nr][r] + bv;
-        if (ch_ok && oz < e.Dout && oy < e.Hout && ox < e.Wout) {
-          e.y[((size_t)((oz * e.os + e.offz) * e.Hy + (oy * e.os + e.offy)) * e.Wy + (ox * e.os + e.offx)) * e.cout_p + ch] = v;
-          s1 += v;
-          s2 += v * v;
+        v[r] = acc[mr][nr][r] + bv;
+        if (ch_ok && oz0 + tz < e.Dout && oy0 + ty < e.Hout && ox0 + tx < e.Wout) {
+          s1 += v[r];
+          s2 += v[r] * v[r];
         }
       }
+      // The MFMA result has 4 pixels x 1 channel per lane.  Transpose 4x4 inside each
+      // lane quad so a lane holds 1 pixel x 4 consecutive channels: one 16-byte store
+      // instead of four 4-byte stores (the epilogue is store-issue bound).
+      {
+        float x, y;
+        x = (j & 1) ? v[0] : v[1]; y = quad_xor1(x); if (j & 1) v[0] = y; else v[1] = y;
+        x = (j & 1) ? v[2] : v[3]; y = quad_xor1(x); if (j & 1) v[2] = y; else v[3] = y;
+        x = (j & 2) ? v[0] : v[2]; y = quad_xor2(x); if (j & 2) v[0] = y; else v[2] = y;
+        x = (j & 2) ? v[1] : v[3]; y = quad_xor2(x); if (j & 2) v[1] = y; else v[3] = y;
+      }
+      const int p = (wave * MR + mr) * 16 + kq * 4 + j;
+      const int tx = p % TX, ty = (p / TX) % TY, tz = p / (TX * TY);
+      const int oz = oz0 + tz, oy = oy0 + ty, ox = ox0 + tx;
+      const int c0 = (nb0 + nr) * 16 + (mrow & ~3);
+      if (c0 < e.cout_p && oz < e.Dout && oy < e.Hout && ox < e.Wout)
+        *reinterpret_cast<float4*>(
+            e.y + ((size_t)((oz * e.os + e.offz) * e.Hy + (oy * e.os + e.offy)) * e.Wy + (ox * e.os + e.offx)) * e.cout_p + c0) =
+            make_float4(v[0], v[1], v[2], v[3]);
     }
     if (e.stats) {
       s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);

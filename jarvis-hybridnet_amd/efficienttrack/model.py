@@ -22,7 +22,7 @@ class _Plan:
                                            w, ctypes.byref(self.handle)))
 
     def close(self):
-        if self.handle:
+        if self.handle and N is not None and N._lib is not None:
             N.lib().jh_efftrack_destroy(self.handle)
             self.handle = None
 

@@ -14,7 +14,7 @@ class _Plan:
         N.check(N.lib().jh_v2v_create(params.handle, b"", joints, t, g, ctypes.byref(self.handle)))
 
     def close(self):
-        if self.handle:
+        if self.handle and N is not None and N._lib is not None:
             N.lib().jh_v2v_destroy(self.handle)
             self.handle = None
 
