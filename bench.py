@@ -53,7 +53,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--time-batch", type=int, default=8, help="multi-view frames per step")
+    ap.add_argument("--time-batch", type=int, default=16, help="multi-view frames per step")
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--exchange", default="alltoall", choices=["alltoall", "allgather"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -191,7 +191,17 @@ def main():
                                 "frac": by / avg_s / 1e9 / PEAK_HBM_GBS, "traffic": None,
                                 "avg_launch_ms": ms / cnt, "launches_per_step": cnt // 3,
                                 "share_of_step": ms / total_ms}
-        line["kernel_breakdown_ms_per_step"] = {k: round(v[0] / 3, 4) for k, v in top[:12]}
+        # HBM bytes of that kernel from the committed PMC passes (rocprofv3 cannot run
+        # inside this process), scaled to this run's time batch
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if name in pmc:
+                line["roofline"]["traffic"] = pmc[name]["hbm_bytes_per_launch"] * T / pmc[name]["time_batch"]
+                line["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+                line["roofline"]["algorithmic_bytes"] = by
+        except (OSError, ValueError):
+            pass
+        line["kernel_breakdown_ms_per_step"] = {k: round(v[0] / 3, 4) for k, v in top[:int(os.environ.get("JH_BENCH_TOP", "12"))]}
         line["kernel_time_ms_per_step"] = total_ms / 3
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
