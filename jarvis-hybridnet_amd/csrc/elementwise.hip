@@ -6,8 +6,8 @@
 //               v2vnet.py:17-19,32-43,54-55)
 //  se_gate     squeeze-excite bottleneck MLP -> per-(n,c) sigmoid gate
 //              (efficientnet.py:107-112)
-//  depthwise   k x k depthwise convolution, stride 1 (efficientnet.py:68-71,
-//              model.py:196-203)
+//  depthwise   k x k depthwise convolution, stride 1, LDS-staged halo tiles
+//              (efficientnet.py:68-71; the BiFPN sep-convs run fused, bifpn_node.hip)
 //  fuse        BiFPN fast-normalised fusion node incl. nearest upsample /
 //              2x2 max-pool of the neighbour level (model.py:309-353,119-125)
 //  maxpool2    2x2/2 max pool (model.py:414-419)
@@ -157,70 +157,108 @@ int launch_se_gate(const double* pool, int N, int C, int Cp, int S, float inv_hw
 }
 
 // ------------------------------------------------------------------- depthwise
+// LDS-staged depthwise k x k (stride 1): a workgroup owns a 16 x 16 pixel tile of one
+// image and a chunk of 32 channels.  The (16+k-1)^2 halo patch is staged once in LDS
+// ([pixel][32 + 4] floats); every thread keeps the k*k weights of its channel quad in
+// registers and produces 1 x 4 output strips, so each staged value is read from LDS
+// (k+3)/4k times per tap instead of once.  Optional InstanceNorm statistics of the
+// output are reduced in the block and added with fp64 atomics.
 template <int K>
-__global__ __launch_bounds__(256) void depthwise_kernel(
+__global__ __launch_bounds__(256) void depthwise_lds_kernel(
     const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
-    double* __restrict__ stats, int H, int W, int Cp, int ppb) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int q = Cp >> 2;
-  const int rows = 256 / q;
+    double* __restrict__ stats, int H, int W, int Cp) {
+  constexpr int T = 16, HT = T + K - 1, CC = 32, SP = CC + 4;
+  extern __shared__ __attribute__((aligned(16))) float sm[];     // [HT*HT][SP]
   const int tid = threadIdx.x;
-  const bool active = tid < rows * q;
-  const int c4 = tid % q, row = tid / q;
-  const int n = blockIdx.y;
-  const int P = H * W;
-  const int p0 = blockIdx.x * ppb;
-  const int p1 = min(P, p0 + ppb);
-  const float* xin = x + (size_t)n * P * Cp;
-  float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
+  const int tiles_x = (W + T - 1) / T;
+  const int ox0 = (blockIdx.x % tiles_x) * T, oy0 = (blockIdx.x / tiles_x) * T;
+  const int c0 = blockIdx.y * CC;
+  const int n = blockIdx.z;
+  const int q = min(CC, Cp - c0) >> 2;             // channel quads in this chunk (<= 8)
+  const float* xin = x + (size_t)n * H * W * Cp;
+  for (int idx = tid; idx < HT * HT * q; idx += 256) {
+    const int c4 = idx % q, pix = idx / q;
+    const int px = pix % HT, py = pix / HT;
+    const int iy = oy0 + py - K / 2, ix = ox0 + px - K / 2;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W)
+      v = *reinterpret_cast<const float4*>(xin + ((size_t)iy * W + ix) * Cp + c0 + c4 * 4);
+    *reinterpret_cast<float4*>(sm + pix * SP + c4 * 4) = v;
+  }
+  const int c4 = tid & 7;                          // fixed channel quad of this thread
+  const bool active = c4 < q;
+  float4 wt[K * K];
   if (active) {
-    float4 wt[K * K];
 #pragma unroll
     for (int t = 0; t < K * K; ++t)
-      wt[t] = *reinterpret_cast<const float4*>(w + (size_t)t * Cp + c4 * 4);
-    for (int p = p0 + row; p < p1; p += rows) {
-      const int oy = p / W, ox = p % W;
-      float4 acc = make_float4(0, 0, 0, 0);
+      wt[t] = *reinterpret_cast<const float4*>(w + (size_t)t * Cp + c0 + c4 * 4);
+  }
+  __syncthreads();
+  float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int g = (tid >> 3) + 32 * j;           // 64 strips: 16 rows x 4 strips of 4 pixels
+      const int ty = g >> 2, tx0 = (g & 3) * 4;
+      float4 acc[4];
+#pragma unroll
+      for (int o = 0; o < 4; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int dy = 0; dy < K; ++dy) {
-        const int iy = oy + dy - K / 2;
-        if (iy < 0 || iy >= H) continue;
+        float4 in[K + 3];
+#pragma unroll
+        for (int i = 0; i < K + 3; ++i)
+          in[i] = *reinterpret_cast<const float4*>(sm + ((ty + dy) * HT + tx0 + i) * SP + c4 * 4);
 #pragma unroll
         for (int dx = 0; dx < K; ++dx) {
-          const int ix = ox + dx - K / 2;
-          if (ix < 0 || ix >= W) continue;
-          const float4 v = *reinterpret_cast<const float4*>(xin + ((size_t)iy * W + ix) * Cp + c4 * 4);
           const float4 k = wt[dy * K + dx];
-          acc.x = fmaf(v.x, k.x, acc.x); acc.y = fmaf(v.y, k.y, acc.y);
-          acc.z = fmaf(v.z, k.z, acc.z); acc.w = fmaf(v.w, k.w, acc.w);
+#pragma unroll
+          for (int o = 0; o < 4; ++o) {
+            acc[o].x = fmaf(in[o + dx].x, k.x, acc[o].x); acc[o].y = fmaf(in[o + dx].y, k.y, acc[o].y);
+            acc[o].z = fmaf(in[o + dx].z, k.z, acc[o].z); acc[o].w = fmaf(in[o + dx].w, k.w, acc[o].w);
+          }
         }
       }
-      *reinterpret_cast<float4*>(y + ((size_t)n * P + p) * Cp + c4 * 4) = acc;
-      s1.x += acc.x; s1.y += acc.y; s1.z += acc.z; s1.w += acc.w;
-      s2.x += acc.x * acc.x; s2.y += acc.y * acc.y; s2.z += acc.z * acc.z; s2.w += acc.w * acc.w;
+      const int oy = oy0 + ty;
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        const int ox = ox0 + tx0 + o;
+        if (oy < H && ox < W) {
+          *reinterpret_cast<float4*>(y + (((size_t)n * H + oy) * W + ox) * Cp + c0 + c4 * 4) = acc[o];
+          s1.x += acc[o].x; s1.y += acc[o].y; s1.z += acc[o].z; s1.w += acc[o].w;
+          s2.x += acc[o].x * acc[o].x; s2.y += acc[o].y * acc[o].y;
+          s2.z += acc[o].z * acc[o].z; s2.w += acc[o].w * acc[o].w;
+        }
+      }
     }
   }
-  if (stats)
-    block_channel_reduce(s1, s2, 2, q, rows, tid, active, stats + (size_t)n * Cp * 2, 2, sm);
+  if (stats) {
+    __syncthreads();                               // the patch is dead: reuse LDS for the reduce
+    // [32 rows][8 quads][2][4]
+    float4* p = reinterpret_cast<float4*>(sm) + ((size_t)(tid >> 3) * 8 + c4) * 2;
+    p[0] = s1; p[1] = s2;
+    __syncthreads();
+    for (int i = tid; i < q * 8; i += 256) {
+      const int comp = i & 3, v = (i >> 2) & 1, cq = i >> 3;
+      float acc = 0.f;
+      for (int r = 0; r < 32; ++r) acc += sm[(((size_t)r * 8 + cq) * 2 + v) * 4 + comp];
+      unsafeAtomicAdd(stats + ((size_t)n * Cp + c0 + cq * 4 + comp) * 2 + v, (double)acc);
+    }
+  }
 }
 
 int launch_depthwise(const Act& x, const float* w, int k, float* y, double* stats, hipStream_t s) {
   JH_REQUIRE(x.D == 1, "depthwise is 2D only");
-  const int P = x.H * x.W;
-  const int q = x.Cp / 4;
-  JH_REQUIRE(q >= 1 && q <= 256, "channel count out of range for depthwise");
-  const int rows = 256 / q;
-  int iters = 4;
-  while ((long)x.N * ((P + rows * iters - 1) / (rows * iters)) > 8192 && iters < 64) iters *= 2;
-  const int ppb = rows * iters;
-  dim3 grid((P + ppb - 1) / ppb, x.N);
-  const size_t sm = stats ? (size_t)rows * q * 8 * sizeof(float) : 0;
+  JH_REQUIRE(k == 3 || k == 5, "depthwise kernel size must be 3 or 5");
+  const int tiles = ((x.H + 15) / 16) * ((x.W + 15) / 16);
+  dim3 grid(tiles, (x.Cp + 31) / 32, x.N);
+  const int ht = 16 + k - 1;
+  size_t lds = (size_t)ht * ht * 36 * sizeof(float);
+  if (lds < 32 * 8 * 8 * sizeof(float)) lds = 32 * 8 * 8 * sizeof(float);
   if (k == 3)
-    hipLaunchKernelGGL(depthwise_kernel<3>, grid, dim3(256), sm, s, x.p, w, y, stats, x.H, x.W, x.Cp, ppb);
-  else if (k == 5)
-    hipLaunchKernelGGL(depthwise_kernel<5>, grid, dim3(256), sm, s, x.p, w, y, stats, x.H, x.W, x.Cp, ppb);
+    hipLaunchKernelGGL(depthwise_lds_kernel<3>, grid, dim3(256), lds, s, x.p, w, y, stats, x.H, x.W, x.Cp);
   else
-    JH_REQUIRE(false, "depthwise kernel size must be 3 or 5");
+    hipLaunchKernelGGL(depthwise_lds_kernel<5>, grid, dim3(256), lds, s, x.p, w, y, stats, x.H, x.W, x.Cp);
   JH_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -124,6 +124,9 @@ __global__ __launch_bounds__(256) void repro_gather_kernel(
 #pragma unroll
   for (int q = 0; q < Q; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
 
+  // cameras are independent: unrolling lets the coarse-table loads and heatmap
+  // gathers of neighbouring cameras overlap (the loop is latency-, not bandwidth-bound)
+#pragma unroll 4
   for (int c = 0; c < C; ++c) {
     const float2* cz = coarse + (size_t)(t * C + c) * nvox_c;
     const float2 p000 = cz[o000 + k0], p001 = cz[o000 + k1];
