@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the multi-GPU (camera-sharded, RCCL) code path even with one rank")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -69,8 +71,12 @@ def main():
                          (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
+        os.environ["NCCL_DEBUG"] = "WARN"          # keep RCCL's version banner off stdout
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
 
     from jarvis_hybridnet_amd import _native as N
@@ -94,7 +100,7 @@ def main():
     common = dict(num_cameras=c["C"], num_joints=c["J"], center_size=c["center"], bbox=c["bbox"],
                   roi_cube_size=c["roi"], grid_spacing=c["spacing"], img_h=c["H"], img_w=c["W"],
                   mean=S.MEAN, std=S.STD, time_batch=T)
-    if world == 1:
+    if not sharded:
         pred = NativePredictor(sd_c, sd_h, **common)
         pred.set_calibration(*[t.to(dev) for t in calib])
         fr = frames.to(dev).contiguous()
@@ -119,14 +125,14 @@ def main():
             return sh.step(fr)
 
     def barrier():
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(max(1, args.warmup)):
         res = step()
     run = step
-    if args.graph and world == 1:
+    if args.graph and not sharded:
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
@@ -139,7 +145,7 @@ def main():
         run()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if sharded:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
@@ -159,13 +165,13 @@ def main():
                    "cameras": c["C"], "frame": [c["H"], c["W"]], "joints": c["J"],
                    "grid": int(c["roi"] / c["spacing"]), "time_batch": T,
                    "frames_per_step": T * n_groups, "valid_frames_last_step": valid,
-                   "parallelism": "single GPU" if world == 1 else
+                   "parallelism": "single GPU" if not sharded else
                    "%d group(s) x %d GPUs: camera-sharded 2D (%d cams/GPU) + RCCL %s of "
                    "heatmaps + frame-sharded 3D" % (n_groups, gs, c["C"] // gs, args.exchange),
                    "launches_per_step": int(pred.launches), "hipgraph": bool(args.graph)},
     }
 
-    if rank == 0 and world == 1:
+    if rank == 0 and not sharded:
         # ---- roofline of the dominant kernel, HIP events around every launch
         recs = []
         for _ in range(3):
@@ -238,10 +244,11 @@ def main():
             line["parity_max_abs_mm_vs_reference_fixture"] = float(
                 np.abs(res[0][0].cpu().numpy() - gold[0]).max())
 
-    if rank == 0:
-        print(json.dumps(line))
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)       # the ONE JSON line, last thing on stdout
 
 
 if __name__ == "__main__":
