@@ -95,7 +95,13 @@ def main():
     sd_c = S.efficienttrack_weights("small", 1, 50)
     sd_h = S.hybridnet_weights("small", c["J"], 51)
     distinct = [S.blob_frames(calib, c["W"], c["H"], c["J"], 52 + i)[0] for i in range(min(T, 2))]
-    frames = torch.stack([distinct[t % len(distinct)] for t in range(T)])      # (T,C,3,H,W)
+
+    def device_frames(cam_lo, cam_n):
+        """(T, cam_n, 3, H, W) on the GPU, assembled there from the distinct frames so
+        the host never holds T copies (T = 64 frames per group at 8 GPUs)."""
+        base = torch.stack([d[cam_lo:cam_lo + cam_n] for d in distinct]).to(dev)
+        idx = torch.arange(T, device=dev) % len(distinct)
+        return base[idx].contiguous()
 
     common = dict(num_cameras=c["C"], num_joints=c["J"], center_size=c["center"], bbox=c["bbox"],
                   roi_cube_size=c["roi"], grid_spacing=c["spacing"], img_h=c["H"], img_w=c["W"],
@@ -103,7 +109,7 @@ def main():
     if not sharded:
         pred = NativePredictor(sd_c, sd_h, **common)
         pred.set_calibration(*[t.to(dev) for t in calib])
-        fr = frames.to(dev).contiguous()
+        fr = device_frames(0, c["C"])
         out = (torch.empty((T, c["J"], 3), device=dev), torch.empty((T, c["J"]), device=dev),
                torch.empty((T,), device=dev, dtype=torch.int32))
 
@@ -116,7 +122,7 @@ def main():
         pred = NativePredictor(sd_c, sd_h, time_batch_3d=T // gs, cam_lo=cam_lo, cam_n=cam_n,
                                **common)
         pred.set_calibration(*[t.to(dev) for t in calib])
-        fr = frames[:, cam_lo:cam_lo + cam_n].to(dev).contiguous()
+        fr = device_frames(cam_lo, cam_n)
         sh = ShardedPredictor(pred, num_cameras=c["C"], num_joints=c["J"], time_batch=T,
                               heat_shape=(pred.Hh, pred.Hh, pred.Jp), rank=grank, world=gs,
                               device=dev, exchange=args.exchange, group=groups[gidx])
@@ -219,10 +225,10 @@ def main():
         kw = dict(center_size=c["center"], bbox=c["bbox"], roi_cube_size=c["roi"],
                   grid_spacing=c["spacing"], mean=S.MEAN, std=S.STD)
         with torch.no_grad():
-            ref = O.predictor3d_forward(sd_c, sd_h, frames[0], *calib, **kw)     # warm-up
+            ref = O.predictor3d_forward(sd_c, sd_h, distinct[0], *calib, **kw)     # warm-up
             n, t0 = 0, time.perf_counter()
             while n < 1 or (time.perf_counter() - t0 < args.cpu_seconds and n < 50):
-                O.predictor3d_forward(sd_c, sd_h, frames[n % len(distinct)], *calib, **kw)
+                O.predictor3d_forward(sd_c, sd_h, distinct[n % len(distinct)], *calib, **kw)
                 n += 1
             cpu_dt = time.perf_counter() - t0
         line["cpu_baseline"] = {"value": n / cpu_dt, "unit": "multi-view frames/s", "cores": cores,
