@@ -138,6 +138,18 @@ int jh_predictor_stage_3d(jh_predictor* pr, const float* heat_all_dev, int t0, f
 /* All three stages for cam_lo = 0, cam_n = num_cameras. */
 int jh_predictor_forward(jh_predictor* pr, const float* frames_dev, float* points_dev,
                          float* conf_dev, int32_t* valid_dev, void* stream);
+/* uint8 ingest (jarvis/prediction/predict3D.py:72-80): the
+ * same three entry points for frames (T,cam_n,H,W,3) uint8 BGR exactly as the video
+ * decoder delivers them.  The `.float().permute(0,3,1,2)[:, [2,1,0]] / 255.` of the
+ * reference driver happens inside the resize / crop kernels, so the fp32 frame (4x the
+ * bytes) is never materialised and only 1 byte per sample crosses PCIe. */
+int jh_predictor_stage_center_u8(jh_predictor* pr, const uint8_t* frames_dev, float* det_dev,
+                                 void* stream);
+int jh_predictor_stage_keypoints_u8(jh_predictor* pr, const uint8_t* frames_dev,
+                                    const float* det_all_dev, float* heat_dev, void* stream);
+int jh_predictor_forward_u8(jh_predictor* pr, const uint8_t* frames_dev, float* points_dev,
+                            float* conf_dev, int32_t* valid_dev, void* stream);
+
 /* Integer path of the last call, for parity tests: center3d float (T,3),
  * center3d int (T,3), center_hm (T,C,2), det (T,C,3).  Any pointer may be NULL. */
 int jh_predictor_debug(jh_predictor* pr, float* center3d_f_dev, int32_t* center3d_i_dev,

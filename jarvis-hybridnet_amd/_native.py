@@ -66,6 +66,9 @@ _SIGS = {
     "jh_profile_get": (c_int, [c_int, c_char_p, c_int, ctypes.POINTER(ctypes.c_double),
                                ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "jh_predictor_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "jh_predictor_stage_center_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "jh_predictor_stage_keypoints_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "jh_predictor_forward_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "jh_predictor_debug": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "jh_predictor_hybridnet_forward": (c_int, [c_void_p] * 9),
     "jh_op_conv": (c_int, [c_int] * 7 + [c_void_p, c_void_p, c_void_p] + [c_int] * 4 +

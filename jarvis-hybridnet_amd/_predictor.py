@@ -46,23 +46,29 @@ class NativePredictor:
 
     # ---- single-GPU forward ----------------------------------------------
     def forward(self, frames, out=None):
-        """frames (T,C,3,H,W) -> points (T,J,3), conf (T,J), valid (T) int32."""
+        """frames (T,C,3,H,W) fp32 RGB, or (T,C,H,W,3) uint8 BGR as decoded
+        -> points (T,J,3), conf (T,J), valid (T) int32."""
         dev = frames.device
         if out is None:
             out = (torch.empty((self.T, self.J, 3), device=dev),
                    torch.empty((self.T, self.J), device=dev),
                    torch.empty((self.T,), device=dev, dtype=torch.int32))
-        N.check(N.lib().jh_predictor_forward(self.handle, N.ptr(frames), N.ptr(out[0]),
-                                             N.ptr(out[1]), N.ptr(out[2]), N.stream()))
+        fn = N.lib().jh_predictor_forward_u8 if frames.dtype == torch.uint8 else \
+            N.lib().jh_predictor_forward
+        N.check(fn(self.handle, N.ptr(frames), N.ptr(out[0]), N.ptr(out[1]), N.ptr(out[2]),
+                   N.stream()))
         return out
 
     # ---- camera-sharded stages -------------------------------------------
     def stage_center(self, frames, det):
-        N.check(N.lib().jh_predictor_stage_center(self.handle, N.ptr(frames), N.ptr(det), N.stream()))
+        fn = N.lib().jh_predictor_stage_center_u8 if frames.dtype == torch.uint8 else \
+            N.lib().jh_predictor_stage_center
+        N.check(fn(self.handle, N.ptr(frames), N.ptr(det), N.stream()))
 
     def stage_keypoints(self, frames, det_all, heat):
-        N.check(N.lib().jh_predictor_stage_keypoints(self.handle, N.ptr(frames), N.ptr(det_all),
-                                                     N.ptr(heat), N.stream()))
+        fn = N.lib().jh_predictor_stage_keypoints_u8 if frames.dtype == torch.uint8 else \
+            N.lib().jh_predictor_stage_keypoints
+        N.check(fn(self.handle, N.ptr(frames), N.ptr(det_all), N.ptr(heat), N.stream()))
 
     def stage_3d(self, heat_all, t0, points, conf, valid):
         N.check(N.lib().jh_predictor_stage_3d(self.handle, N.ptr(heat_all), t0, N.ptr(points),

@@ -285,14 +285,14 @@ int jh_predictor_set_calibration(jh_predictor* pr, const float* cam_dev, const f
   return 0;
 }
 
-int jh_predictor_stage_center(jh_predictor* pr, const float* frames_dev, float* det_dev,
-                              void* stream) {
+static int stage_center_impl(jh_predictor* pr, const void* frames_dev, int src_u8, float* det_dev,
+                             void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   JH_REQUIRE(pr->center, "predictor was created without CenterDetect weights");
   const int N = pr->T * pr->Cloc, S = pr->cfg.center_size;
-  JH_PROF("preprocess_resize", 0.0, (double)N * S * S * (12.0 * 4 + 3 * 4),
-          launch_preprocess_resize(frames_dev, pr->center->input.p, N, pr->cfg.img_h, pr->cfg.img_w,
-                                   S, pr->cfg.mean, pr->cfg.std, s));
+  JH_PROF("preprocess_resize", 0.0, (double)N * S * S * (12.0 * (src_u8 ? 1 : 4) + 3 * 4),
+          launch_preprocess_resize(frames_dev, src_u8, pr->center->input.p, N, pr->cfg.img_h,
+                                   pr->cfg.img_w, S, pr->cfg.mean, pr->cfg.std, s));
   if (pr->center->run(s)) return 1;
   const Act& h = pr->center->heat;
   JH_PROF("center_argmax", 0.0, 4.0 * N * h.H * h.W,
@@ -300,8 +300,17 @@ int jh_predictor_stage_center(jh_predictor* pr, const float* frames_dev, float* 
   return 0;
 }
 
-int jh_predictor_stage_keypoints(jh_predictor* pr, const float* frames_dev,
-                                 const float* det_all_dev, float* heat_dev, void* stream) {
+int jh_predictor_stage_center(jh_predictor* pr, const float* frames_dev, float* det_dev,
+                              void* stream) {
+  return stage_center_impl(pr, frames_dev, 0, det_dev, stream);
+}
+int jh_predictor_stage_center_u8(jh_predictor* pr, const uint8_t* frames_dev, float* det_dev,
+                                 void* stream) {
+  return stage_center_impl(pr, frames_dev, 1, det_dev, stream);
+}
+
+static int stage_keypoints_impl(jh_predictor* pr, const void* frames_dev, int src_u8,
+                                const float* det_all_dev, float* heat_dev, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   const auto& c = pr->cfg;
   // preds * (downsampling_scale * 2), jarvis3D.py:138-141,158-160
@@ -313,14 +322,23 @@ int jh_predictor_stage_keypoints(jh_predictor* pr, const float* frames_dev,
   if (det_all_dev != pr->det_all)
     JH_CHECK_HIP(hipMemcpyAsync(pr->det_all, det_all_dev, (size_t)pr->T * pr->C * 3 * sizeof(float),
                                 hipMemcpyDeviceToDevice, s));
-  JH_PROF("preprocess_crop", 0.0, (double)pr->T * pr->Cloc * pr->B * pr->B * 24.0,
-          launch_preprocess_crop(frames_dev, pr->chm, pr->kp->input.p, pr->T, pr->Cloc, pr->C,
+  JH_PROF("preprocess_crop", 0.0, (double)pr->T * pr->Cloc * pr->B * pr->B * (src_u8 ? 15.0 : 24.0),
+          launch_preprocess_crop(frames_dev, src_u8, pr->chm, pr->kp->input.p, pr->T, pr->Cloc, pr->C,
                                  c.cam_lo, c.img_h, c.img_w, pr->B, c.mean, c.std, s));
   if (pr->kp->run(s)) return 1;
   if (heat_dev && heat_dev != pr->kp->heat.p)
     JH_CHECK_HIP(hipMemcpyAsync(heat_dev, pr->kp->heat.p, pr->kp->heat.bytes(),
                                 hipMemcpyDeviceToDevice, s));
   return 0;
+}
+
+int jh_predictor_stage_keypoints(jh_predictor* pr, const float* frames_dev,
+                                 const float* det_all_dev, float* heat_dev, void* stream) {
+  return stage_keypoints_impl(pr, frames_dev, 0, det_all_dev, heat_dev, stream);
+}
+int jh_predictor_stage_keypoints_u8(jh_predictor* pr, const uint8_t* frames_dev,
+                                    const float* det_all_dev, float* heat_dev, void* stream) {
+  return stage_keypoints_impl(pr, frames_dev, 1, det_all_dev, heat_dev, stream);
 }
 
 int jh_predictor_stage_3d(jh_predictor* pr, const float* heat_all_dev, int t0, float* points_dev,
@@ -334,13 +352,21 @@ int jh_predictor_stage_3d(jh_predictor* pr, const float* heat_all_dev, int t0, f
   return 0;
 }
 
-int jh_predictor_forward(jh_predictor* pr, const float* frames_dev, float* points_dev,
-                         float* conf_dev, int32_t* valid_dev, void* stream) {
+static int forward_impl(jh_predictor* pr, const void* frames_dev, int src_u8, float* points_dev,
+                        float* conf_dev, int32_t* valid_dev, void* stream) {
   JH_REQUIRE(pr->Cloc == pr->C && pr->cfg.cam_lo == 0, "forward needs all cameras local");
   JH_REQUIRE(pr->T3 == pr->T, "forward needs time_batch_3d == time_batch");
-  if (jh_predictor_stage_center(pr, frames_dev, pr->det_all, stream)) return 1;
-  if (jh_predictor_stage_keypoints(pr, frames_dev, pr->det_all, nullptr, stream)) return 1;
+  if (stage_center_impl(pr, frames_dev, src_u8, pr->det_all, stream)) return 1;
+  if (stage_keypoints_impl(pr, frames_dev, src_u8, pr->det_all, nullptr, stream)) return 1;
   return jh_predictor_stage_3d(pr, pr->kp->heat.p, 0, points_dev, conf_dev, valid_dev, stream);
+}
+int jh_predictor_forward(jh_predictor* pr, const float* frames_dev, float* points_dev,
+                         float* conf_dev, int32_t* valid_dev, void* stream) {
+  return forward_impl(pr, frames_dev, 0, points_dev, conf_dev, valid_dev, stream);
+}
+int jh_predictor_forward_u8(jh_predictor* pr, const uint8_t* frames_dev, float* points_dev,
+                            float* conf_dev, int32_t* valid_dev, void* stream) {
+  return forward_impl(pr, frames_dev, 1, points_dev, conf_dev, valid_dev, stream);
 }
 
 int jh_predictor_debug(jh_predictor* pr, float* center3d_f_dev, int32_t* center3d_i_dev,

@@ -16,9 +16,25 @@
 namespace jh {
 
 // ------------------------------------------------------------------ preprocess
-// frames: [N][3][H][W] fp32 RGB in [0,1]; out: [N][S][S][8] channel-last.
+// Two frame formats: SRC = 0: [N][3][H][W] fp32 RGB in [0,1] (the API input of
+// JarvisPredictor3D.forward); SRC = 1: [N][H][W][3] uint8 BGR as the video decoder
+// delivers it, converted like predict3D.py:79-80 (`.float()...[:, [2,1,0]] / 255.`) on
+// the fly, so the 4x larger fp32 frame never exists.
+template <int SRC>
+__device__ __forceinline__ float frame_px(const void* frames, size_t n, int c, int y, int x, int H,
+                                          int W) {
+  if (SRC == 0)
+    return static_cast<const float*>(frames)[((n * 3 + c) * H + y) * W + x];
+  const unsigned char* p = static_cast<const unsigned char*>(frames) + ((n * H + y) * W + x) * 3;
+  // the reference driver divides on the GPU, where torch evaluates `x / 255.` as
+  // x * (1.f / 255.f) (division by a host scalar is a multiplication by its reciprocal)
+  return __fmul_rn((float)p[2 - c], __fdiv_rn(1.f, 255.f));
+}
+
+// out: [N][S][S][8] channel-last.
+template <int SRC>
 __global__ __launch_bounds__(256) void preprocess_resize_kernel(
-    const float* __restrict__ frames, float* __restrict__ out, int N, int H, int W, int S,
+    const void* __restrict__ frames, float* __restrict__ out, int N, int H, int W, int S,
     float sy, float sx, float3 mean, float3 stdv) {
   const size_t total = (size_t)N * S * S;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -34,9 +50,10 @@ __global__ __launch_bounds__(256) void preprocess_resize_kernel(
     float r[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const float* p = frames + ((size_t)n * 3 + c) * H * W;
-      const float a = __fmaf_rn(p[(size_t)y0 * W + x0], lx0, __fmul_rn(p[(size_t)y0 * W + x1], lx1));
-      const float b = __fmaf_rn(p[(size_t)y1 * W + x0], lx0, __fmul_rn(p[(size_t)y1 * W + x1], lx1));
+      const float p00 = frame_px<SRC>(frames, n, c, y0, x0, H, W), p01 = frame_px<SRC>(frames, n, c, y0, x1, H, W);
+      const float p10 = frame_px<SRC>(frames, n, c, y1, x0, H, W), p11 = frame_px<SRC>(frames, n, c, y1, x1, H, W);
+      const float a = __fmaf_rn(p00, lx0, __fmul_rn(p01, lx1));
+      const float b = __fmaf_rn(p10, lx0, __fmul_rn(p11, lx1));
       const float v = __fmaf_rn(a, ly0, __fmul_rn(b, ly1));
       r[c] = __fdiv_rn(__fsub_rn(v, mv[c]), sv[c]);
     }
@@ -46,21 +63,26 @@ __global__ __launch_bounds__(256) void preprocess_resize_kernel(
   }
 }
 
-int launch_preprocess_resize(const float* frames, float* out, int N, int H, int W, int S,
+int launch_preprocess_resize(const void* frames, int src_u8, float* out, int N, int H, int W, int S,
                              const float* mean, const float* stdv, hipStream_t s) {
   const size_t total = (size_t)N * S * S;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(preprocess_resize_kernel, dim3(blocks), dim3(256), 0, s, frames, out, N, H, W,
-                     S, (float)H / (float)S, (float)W / (float)S,
-                     make_float3(mean[0], mean[1], mean[2]), make_float3(stdv[0], stdv[1], stdv[2]));
+  const float3 m = make_float3(mean[0], mean[1], mean[2]), sd = make_float3(stdv[0], stdv[1], stdv[2]);
+  if (src_u8)
+    hipLaunchKernelGGL(preprocess_resize_kernel<1>, dim3(blocks), dim3(256), 0, s, frames, out, N, H,
+                       W, S, (float)H / (float)S, (float)W / (float)S, m, sd);
+  else
+    hipLaunchKernelGGL(preprocess_resize_kernel<0>, dim3(blocks), dim3(256), 0, s, frames, out, N, H,
+                       W, S, (float)H / (float)S, (float)W / (float)S, m, sd);
   JH_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
-// frames: [T][Cloc][3][H][W]; center_hm: [T][C][2] (all cameras); out [T*Cloc][B][B][8]
+// frames: [T][Cloc] images; center_hm: [T][C][2] (all cameras); out [T*Cloc][B][B][8]
+template <int SRC>
 __global__ __launch_bounds__(256) void preprocess_crop_kernel(
-    const float* __restrict__ frames, const int* __restrict__ center_hm, float* __restrict__ out,
+    const void* __restrict__ frames, const int* __restrict__ center_hm, float* __restrict__ out,
     int T, int Cloc, int C, int cam0, int H, int W, int B, float3 mean, float3 stdv) {
   const size_t total = (size_t)T * Cloc * B * B;
   const int hw = B / 2;
@@ -76,7 +98,7 @@ __global__ __launch_bounds__(256) void preprocess_crop_kernel(
     const bool ok = ix >= 0 && ix < W && iy >= 0 && iy < H;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const float v = ok ? frames[(((size_t)n * 3 + c) * H + iy) * W + ix] : 0.f;
+      const float v = ok ? frame_px<SRC>(frames, n, c, iy, ix, H, W) : 0.f;
       r[c] = __fdiv_rn(__fsub_rn(v, mv[c]), sv[c]);
     }
     float4* o = reinterpret_cast<float4*>(out + i * 8);
@@ -85,15 +107,19 @@ __global__ __launch_bounds__(256) void preprocess_crop_kernel(
   }
 }
 
-int launch_preprocess_crop(const float* frames, const int* center_hm, float* out, int T, int Cloc,
-                           int C, int cam0, int H, int W, int B, const float* mean,
+int launch_preprocess_crop(const void* frames, int src_u8, const int* center_hm, float* out, int T,
+                           int Cloc, int C, int cam0, int H, int W, int B, const float* mean,
                            const float* stdv, hipStream_t s) {
   const size_t total = (size_t)T * Cloc * B * B;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(preprocess_crop_kernel, dim3(blocks), dim3(256), 0, s, frames, center_hm, out,
-                     T, Cloc, C, cam0, H, W, B, make_float3(mean[0], mean[1], mean[2]),
-                     make_float3(stdv[0], stdv[1], stdv[2]));
+  const float3 m = make_float3(mean[0], mean[1], mean[2]), sd = make_float3(stdv[0], stdv[1], stdv[2]);
+  if (src_u8)
+    hipLaunchKernelGGL(preprocess_crop_kernel<1>, dim3(blocks), dim3(256), 0, s, frames, center_hm,
+                       out, T, Cloc, C, cam0, H, W, B, m, sd);
+  else
+    hipLaunchKernelGGL(preprocess_crop_kernel<0>, dim3(blocks), dim3(256), 0, s, frames, center_hm,
+                       out, T, Cloc, C, cam0, H, W, B, m, sd);
   JH_CHECK_HIP(hipGetLastError());
   return 0;
 }

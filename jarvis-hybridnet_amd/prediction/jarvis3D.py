@@ -67,9 +67,28 @@ class JarvisPredictor3D(nn.Module):
             return None, None
         return points, conf
 
+    def forward_uint8(self, imgs_bgr, cameraMatrices, intrinsicMatrices, distortionCoefficients):
+        """imgs_bgr (C,H,W,3) uint8 BGR exactly as the video decoder delivers them
+        (predict3D.py:72-78).  Same result as forward() on
+        `imgs_bgr.float().permute(0,3,1,2)[:, [2,1,0]] / 255.` (predict3D.py:79-80); the
+        conversion runs inside the resize / crop kernels."""
+        x = N.dev(imgs_bgr, torch.uint8)
+        pr = self.native(x.shape[1], x.shape[2])
+        pr.set_calibration(cameraMatrices, intrinsicMatrices, distortionCoefficients)
+        points, conf, valid = pr.forward(x.unsqueeze(0))
+        if int(valid[0].item()) == 0:
+            return None, None
+        return points, conf
+
     def forward_batch(self, imgs, cameraMatrices, intrinsicMatrices, distortionCoefficients):
-        """Throughput form: imgs (T,C,3,H,W) independent time steps -> points (T,J,3),
-        confidences (T,J), valid (T) int32; no host synchronisation."""
+        """Throughput form: imgs (T,C,3,H,W) fp32 RGB or (T,C,H,W,3) uint8 BGR,
+        independent time steps -> points (T,J,3), confidences (T,J), valid (T) int32;
+        no host synchronisation."""
+        if imgs.dtype == torch.uint8:
+            x = N.dev(imgs, torch.uint8)
+            pr = self.native(x.shape[2], x.shape[3], time_batch=x.shape[0])
+            pr.set_calibration(cameraMatrices, intrinsicMatrices, distortionCoefficients)
+            return pr.forward(x)
         x = N.dev(imgs)
         pr = self.native(x.shape[3], x.shape[4], time_batch=x.shape[0])
         pr.set_calibration(cameraMatrices, intrinsicMatrices, distortionCoefficients)

@@ -141,3 +141,25 @@ def test_sharded_stages_emulated_two_ranks():
         ec = (conf - rc[r * T3:(r + 1) * T3]).abs().max().item()
         report("sharded_emulated", rank=r, points_mm=ep, conf=ec)
         assert ep < 1e-4 and ec < 1e-6
+
+
+def test_predictor3d_uint8_ingest():
+    """frames as uint8 BGR (C,H,W,3) straight from the decoder.
+    Must equal the fp32 path fed the reference driver's conversion
+    (predict3D.py:79-80) bit for bit -- the conversion is the same arithmetic, only
+    done inside the resize / crop kernels."""
+    from jarvis_hybridnet_amd.prediction.jarvis3D import JarvisPredictor3D
+    c = cases.PREDICTOR_CASES["cfg2"]
+    inp = cases.predictor_inputs("cfg2")
+    u8 = (inp["imgs"].permute(0, 2, 3, 1)[..., [2, 1, 0]] * 255).round().to(torch.uint8).contiguous()
+    ref_in = cuda(u8).float().permute(0, 3, 1, 2)[:, [2, 1, 0]] / 255.
+    pred = JarvisPredictor3D(make_cfg(c, c["center_size"]), inp["sd_center"], inp["sd_hybrid"])
+    dev = [cuda(inp[k]) for k in ("cam", "intr", "dist")]
+    p0, c0 = pred(ref_in.contiguous(), *dev)
+    p1, c1 = pred.forward_uint8(cuda(u8), *dev)
+    torch.cuda.synchronize()
+    assert p0 is not None and p1 is not None
+    assert torch.equal(p0, p1) and torch.equal(c0, c1)
+    pts, conf, valid = pred.forward_batch(cuda(torch.stack([u8, u8])), *dev)
+    torch.cuda.synchronize()
+    assert int(valid.sum()) == 2 and (pts[1] - p0[0]).abs().max().item() < 1e-4
