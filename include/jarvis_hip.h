@@ -163,6 +163,22 @@ int jh_predictor_hybridnet_forward(jh_predictor* pr, const float* crops_dev,
                                    float* heatmap_final_dev, float* heatmaps_padded_dev,
                                    float* points_dev, float* conf_dev, void* stream);
 
+/* ---- JarvisPredictor2D  (jarvis/prediction/jarvis2D.py:20-44,102-155)
+ * Single-camera 2D pose: resize -> CenterDetect -> argmax -> crop -> KeypointDetect ->
+ * per-joint argmax.  `time_batch` independent images per call (the reference's call is
+ * 1); num_cameras / roi / spacing / cam_* of the config are ignored.
+ * frames (T,3,H,W) fp32 RGB [or (T,H,W,3) uint8 BGR] -> points2D (T,J,2) int32 full-frame
+ * pixels, conf (T,J), valid (T) int32 (0 = centre maxval <= 40: the reference returns
+ * (None, None), jarvis2D.py:121,150-153). */
+typedef struct jh_predictor2d jh_predictor2d;
+int jh_predictor2d_create(const jh_params* center_params, const jh_params* kp_params,
+                          const jh_predictor_config* cfg, jh_predictor2d** out);
+void jh_predictor2d_destroy(jh_predictor2d* pr);
+int jh_predictor2d_forward(jh_predictor2d* pr, const float* frames_dev, int32_t* points_dev,
+                           float* conf_dev, int32_t* valid_dev, void* stream);
+int jh_predictor2d_forward_u8(jh_predictor2d* pr, const uint8_t* frames_dev, int32_t* points_dev,
+                              float* conf_dev, int32_t* valid_dev, void* stream);
+
 /* ---- per-launch timing (HIP events on the launch stream; used by bench.py for
  * the roofline figures).  begin() switches recording on for every kernel the
  * library launches from this process; end() synchronises and returns the number

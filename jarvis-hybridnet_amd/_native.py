@@ -69,6 +69,11 @@ _SIGS = {
     "jh_predictor_stage_center_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "jh_predictor_stage_keypoints_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "jh_predictor_forward_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "jh_predictor2d_create": (c_int, [c_void_p, c_void_p, ctypes.POINTER(PredictorConfig),
+                                      ctypes.POINTER(c_void_p)]),
+    "jh_predictor2d_destroy": (None, [c_void_p]),
+    "jh_predictor2d_forward": (c_int, [c_void_p] * 6),
+    "jh_predictor2d_forward_u8": (c_int, [c_void_p] * 6),
     "jh_predictor_debug": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "jh_predictor_hybridnet_forward": (c_int, [c_void_p] * 9),
     "jh_op_conv": (c_int, [c_int] * 7 + [c_void_p, c_void_p, c_void_p] + [c_int] * 4 +

@@ -402,6 +402,82 @@ int jh_predictor_hybridnet_forward(jh_predictor* pr, const float* crops_dev,
   return pr->run_3d(pr->kp->heat.p, 0, heatmap_final_dev, points_dev, conf_dev, s);
 }
 
+// ----------------------------------------------------------------- 2D predictor
+}  // extern "C"
+
+struct jh_predictor2d {
+  jh_predictor_config cfg{};
+  int T = 0, J = 0, B = 0;
+  std::unique_ptr<EffTrackPlan> center, kp;
+  Scratch mem;
+  float* det = nullptr;
+  int *chm = nullptr, *valid = nullptr;
+};
+
+extern "C" {
+
+int jh_predictor2d_create(const jh_params* center_params, const jh_params* kp_params,
+                          const jh_predictor_config* cfg, jh_predictor2d** out) {
+  JH_REQUIRE(center_params && kp_params && cfg && out, "bad argument");
+  std::unique_ptr<jh_predictor2d> pr(new jh_predictor2d());
+  pr->cfg = *cfg;
+  pr->T = cfg->time_batch; pr->J = cfg->num_joints; pr->B = cfg->bbox;
+  JH_REQUIRE(pr->T >= 1, "batch");
+  JH_REQUIRE(cfg->img_w >= pr->B + 1 && cfg->img_h >= pr->B + 1, "image smaller than the bounding box");
+  pr->center.reset(new EffTrackPlan());
+  if (pr->center->build(center_params->map, "", cfg->center_model, 1, pr->T, cfg->center_size,
+                        cfg->center_size)) return 1;
+  pr->kp.reset(new EffTrackPlan());
+  if (pr->kp->build(kp_params->map, "", cfg->kp_model, pr->J, pr->T, pr->B, pr->B)) return 1;
+  if (pr->mem.get(reinterpret_cast<void**>(&pr->det), (size_t)pr->T * 3 * sizeof(float))) return 1;
+  if (pr->mem.get(reinterpret_cast<void**>(&pr->chm), (size_t)pr->T * 2 * sizeof(int))) return 1;
+  if (pr->mem.get(reinterpret_cast<void**>(&pr->valid), (size_t)pr->T * sizeof(int))) return 1;
+  JH_CHECK_HIP(hipDeviceSynchronize());
+  *out = pr.release();
+  return 0;
+}
+
+void jh_predictor2d_destroy(jh_predictor2d* pr) { delete pr; }
+
+static int forward2d_impl(jh_predictor2d* pr, const void* frames, int src_u8, int32_t* points_dev,
+                          float* conf_dev, int32_t* valid_dev, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const auto& c = pr->cfg;
+  const int S = c.center_size;
+  JH_PROF("preprocess_resize", 0.0, (double)pr->T * S * S * 24.0,
+          launch_preprocess_resize(frames, src_u8, pr->center->input.p, pr->T, c.img_h, c.img_w, S,
+                                   c.mean, c.std, s));
+  if (pr->center->run(s)) return 1;
+  const Act& h = pr->center->heat;
+  JH_PROF("center_argmax", 0.0, 4.0 * pr->T * h.H * h.W,
+          launch_center_argmax(h.p, pr->det, pr->T, h.H, h.W, h.Cp, s));
+  // img_size / float(IMAGE_SIZE) in fp32 (jarvis2D.py:106-109)
+  const float sx = (float)c.img_w / (float)S, sy = (float)c.img_h / (float)S;
+  if (launch_center2d(pr->det, pr->chm, pr->valid, pr->T, sx, sy, pr->B / 2, c.img_w, c.img_h, s))
+    return 1;
+  JH_PROF("preprocess_crop", 0.0, (double)pr->T * pr->B * pr->B * 24.0,
+          launch_preprocess_crop(frames, src_u8, pr->chm, pr->kp->input.p, pr->T, 1, 1, 0, c.img_h,
+                                 c.img_w, pr->B, c.mean, c.std, s));
+  if (pr->kp->run(s)) return 1;
+  const Act& k = pr->kp->heat;
+  JH_PROF("joint_argmax", 0.0, 4.0 * pr->T * k.H * k.W * pr->J,
+          launch_joint_argmax(k.p, pr->chm, points_dev, conf_dev, pr->T, pr->J, k.Cp, k.H, k.W,
+                              pr->B / 2, s));
+  if (valid_dev)
+    JH_CHECK_HIP(hipMemcpyAsync(valid_dev, pr->valid, (size_t)pr->T * sizeof(int),
+                                hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
+int jh_predictor2d_forward(jh_predictor2d* pr, const float* frames_dev, int32_t* points_dev,
+                           float* conf_dev, int32_t* valid_dev, void* stream) {
+  return forward2d_impl(pr, frames_dev, 0, points_dev, conf_dev, valid_dev, stream);
+}
+int jh_predictor2d_forward_u8(jh_predictor2d* pr, const uint8_t* frames_dev, int32_t* points_dev,
+                              float* conf_dev, int32_t* valid_dev, void* stream) {
+  return forward2d_impl(pr, frames_dev, 1, points_dev, conf_dev, valid_dev, stream);
+}
+
 // ------------------------------------------------------------------- profiling
 int jh_profile_begin(void) {
   Profiler& pf = profiler();

@@ -169,6 +169,78 @@ int launch_center_argmax(const float* heat, float* det, int N, int Hh, int Wh, i
   return 0;
 }
 
+// ------------------------------------------------------- 2D predictor glue kernels
+// JarvisPredictor2D (jarvis/prediction/jarvis2D.py:121-129): crop centre of each image
+// from its centre detection: trunc((x, y) * scale * 2), clamped to
+// [hw, size - hw - 1]; valid = maxval > 40.
+__global__ void center2d_kernel(const float* __restrict__ det, int* __restrict__ center_hm,
+                                int* __restrict__ valid, int T, float sx, float sy, int hw, int W,
+                                int H) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const float* d = det + (size_t)t * 3;
+  int cx = (int)__fmul_rn(__fmul_rn(d[0], sx), 2.f);
+  int cy = (int)__fmul_rn(__fmul_rn(d[1], sy), 2.f);
+  cx = min(max(cx, hw), W - hw - 1);
+  cy = min(max(cy, hw), H - hw - 1);
+  center_hm[t * 2 + 0] = cx;
+  center_hm[t * 2 + 1] = cy;
+  valid[t] = d[2] > 40.f ? 1 : 0;
+}
+
+int launch_center2d(const float* det, int* center_hm, int* valid, int T, float sx, float sy, int hw,
+                    int W, int H, hipStream_t s) {
+  hipLaunchKernelGGL(center2d_kernel, dim3((T + 63) / 64), dim3(64), 0, s, det, center_hm, valid, T,
+                     sx, sy, hw, W, H);
+  JH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// Per-joint argmax of the keypoint heatmaps [T][Hh][Wh][Jp] (jarvis2D.py:139-149):
+// points2D = (m % Hh, m // Wh) * 2 + centerHM - hw, confidence = min(max, 255) / 255.
+// One block per (joint, image); the lowest index wins among equal maxima.
+__global__ __launch_bounds__(256) void joint_argmax_kernel(
+    const float* __restrict__ heat, const int* __restrict__ center_hm, int* __restrict__ points,
+    float* __restrict__ conf, int J, int Jp, int Hh, int Wh, int hw) {
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  const int j = blockIdx.x, t = blockIdx.y;
+  const int P = Hh * Wh;
+  const float* h = heat + (size_t)t * P * Jp + j;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int p = threadIdx.x; p < P; p += blockDim.x) {
+    const float v = h[(size_t)p * Jp];
+    if (v > best || (v == best && p < bi)) { best = v; bi = p; }
+  }
+  sv[threadIdx.x] = best; si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      const float v = sv[threadIdx.x + s];
+      const int ii = si[threadIdx.x + s];
+      if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && ii < si[threadIdx.x])) {
+        sv[threadIdx.x] = v; si[threadIdx.x] = ii;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int m = si[0];
+    points[((size_t)t * J + j) * 2 + 0] = (m % Hh) * 2 + center_hm[t * 2 + 0] - hw;
+    points[((size_t)t * J + j) * 2 + 1] = (m / Wh) * 2 + center_hm[t * 2 + 1] - hw;
+    conf[(size_t)t * J + j] = __fdiv_rn(fminf(sv[0], 255.f), 255.f);
+  }
+}
+
+int launch_joint_argmax(const float* heat, const int* center_hm, int* points, float* conf, int T,
+                        int J, int Jp, int Hh, int Wh, int hw, hipStream_t s) {
+  hipLaunchKernelGGL(joint_argmax_kernel, dim3(J, T), dim3(256), 0, s, heat, center_hm, points, conf,
+                     J, Jp, Hh, Wh, hw);
+  JH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 // ---------------------------------------------------------------- triangulation
 // Smallest-eigenvalue eigenvector of a symmetric 4x4 matrix by cyclic Jacobi in
 // fp64.  A^T A of the weighted DLT system shares its right singular vectors with

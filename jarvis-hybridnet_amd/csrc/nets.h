@@ -25,6 +25,10 @@ int launch_preprocess_crop(const void* frames, int src_u8, const int* center_hm,
                            const float* stdv, hipStream_t s);
 int launch_center_argmax(const float* heat, float* det, int N, int Hh, int Wh, int Cp,
                          hipStream_t s);
+int launch_center2d(const float* det, int* center_hm, int* valid, int T, float sx, float sy, int hw,
+                    int W, int H, hipStream_t s);
+int launch_joint_argmax(const float* heat, const int* center_hm, int* points, float* conf, int T,
+                        int J, int Jp, int Hh, int Wh, int hw, hipStream_t s);
 int launch_triangulate(const float* det, const float* cam, const float* intr, const float* dist,
                        float* center3d_f, int* center3d_i, int* center_hm, int* valid, int T, int C,
                        float sx2, float sy2, float wdiv, int hw, int W, int H, hipStream_t s);

@@ -561,3 +561,49 @@ def predictor3d_forward(sd_center, sd_hybrid, imgs, cam_m, intr, dist, *,
     if intermediates is not None:
         intermediates.update(heatmaps_padded=hm_pad, heatmap_final=final)
     return pts, conf
+
+
+def predictor2d_forward(sd_center, sd_kp, img, *, center_size, bbox, mean, std,
+                        center_model="small", kp_model="small",
+                        intermediates=None):
+    """JarvisPredictor2D.forward, prediction/jarvis2D.py:102-155.
+
+    img (1,3,H,W) RGB in [0,1] -> (points2D (J,2) int64 pixels, confidences
+    (J,)) or (None, None) when the centre heatmap maximum is <= 40.
+    """
+    hw = int(bbox / 2)
+    mean_t = torch.tensor(mean).view(3, 1, 1)
+    std_t = torch.tensor(std).view(3, 1, 1)
+    img_size = torch.tensor([img.shape[3], img.shape[2]])
+    scale = torch.tensor([img_size[0] / float(center_size),
+                          img_size[1] / float(center_size)]).float()
+    small = F.interpolate(img, size=[center_size, center_size],
+                          mode="bilinear", align_corners=False)
+    small = (small - mean_t) / std_t
+    hm = efficienttrack_forward(sd_center, small, center_model,
+                                want_res1=False)[1]
+    flat = hm.view(hm.shape[0], hm.shape[1], -1)
+    m = flat.argmax(2).view(flat.shape[0], flat.shape[1], 1)
+    maxval = flat.gather(2, m).squeeze()
+    if intermediates is not None:
+        intermediates.update(center_heatmap=hm, maxval=maxval.clone())
+    if not maxval > 40:
+        return None, None
+    chm = torch.cat((m % hm.shape[2], m // hm.shape[3]),
+                    dim=2).squeeze() * scale * 2
+    chm = chm.int()
+    chm[0] = torch.clamp(chm[0], hw, img_size[0] - hw - 1)
+    chm[1] = torch.clamp(chm[1], hw, img_size[1] - hw - 1)
+    cx, cy = int(chm[0]), int(chm[1])
+    crop = img[:, :, cy - hw:cy + hw, cx - hw:cx + hw]
+    crop = (crop - mean_t) / std_t
+    kh = efficienttrack_forward(sd_kp, crop, kp_model, want_res1=False)[1]
+    kflat = kh.view(kh.shape[0], kh.shape[1], -1)
+    km = kflat.argmax(2).view(kflat.shape[0], kflat.shape[1], 1)
+    pts = torch.cat((km % kh.shape[2], km // kh.shape[3]), dim=2).squeeze() * 2
+    conf = kflat.gather(2, km).squeeze()
+    conf = torch.clamp(conf, max=255.) / 255.
+    pts = pts + chm - hw
+    if intermediates is not None:
+        intermediates.update(center_hm=chm.clone(), kp_heatmap=kh)
+    return pts, conf

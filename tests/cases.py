@@ -124,3 +124,24 @@ def predictor_inputs(tag):
     imgs, joints, centre = S.blob_frames(calib, c["W"], c["H"], c["J"], c["fseed"])
     return dict(sd_center=sd_c, sd_hybrid=sd_h, imgs=imgs, cam=calib[0],
                 intr=calib[1], dist=calib[2], joints=joints, centre=centre)
+
+
+# JarvisPredictor2D: one camera of the cfg2 rig, 12 joints
+# like BASELINE configs[0]
+PREDICTOR2D_CASES = {
+    "cam0_j12": dict(J=12, bbox=256, center_size=256, W=640, H=512, focal=900.0, cseed=50,
+                     kseed=1, fseed=53, cam=0),
+    "cam2_j12": dict(J=12, bbox=256, center_size=256, W=640, H=512, focal=900.0, cseed=50,
+                     kseed=1, fseed=53, cam=2),
+    "cam0_none": dict(J=12, bbox=256, center_size=256, W=640, H=512, focal=900.0, cseed=50,
+                      kseed=1, fseed=53, cam=0, deconv_std=0.05, expect_none=True),
+}
+
+
+def predictor2d_inputs(tag):
+    c = PREDICTOR2D_CASES[tag]
+    calib = S.ring_calibration(4, c["W"], c["H"], c["focal"])
+    sd_c = S.efficienttrack_weights("small", 1, c["cseed"], deconv_std=c.get("deconv_std", 1.2))
+    sd_k = S.efficienttrack_weights("small", c["J"], c["kseed"])
+    imgs, _, _ = S.blob_frames(calib, c["W"], c["H"], 23, c["fseed"])
+    return dict(sd_center=sd_c, sd_kp=sd_k, img=imgs[c["cam"]:c["cam"] + 1].contiguous())

@@ -344,7 +344,46 @@ def case_hybridnet():
     save("hybridnet", out)
 
 
-ALL = dict(state_spec=case_state_spec, efficienttrack=case_efficienttrack,
+def case_predictor2d():
+    from jarvis.prediction.jarvis2D import JarvisPredictor2D
+    out, meta = {}, {}
+    for tag, c in cases.PREDICTOR2D_CASES.items():
+        cfg = R.make_cfg(num_cameras=1, num_joints=c["J"], bbox=c["bbox"],
+                         center_size=c["center_size"])
+        inp = cases.predictor2d_inputs(tag)
+        with tempfile.TemporaryDirectory() as tmp:
+            pc, pk = os.path.join(tmp, "c.pth"), os.path.join(tmp, "k.pth")
+            torch.save(inp["sd_center"], pc)
+            torch.save(inp["sd_kp"], pk)
+            pred = JarvisPredictor2D(cfg, pc, pk, "off")
+        with torch.no_grad():
+            pts, conf = pred(inp["img"])
+            inter = {}
+            opts, oconf = O.predictor2d_forward(
+                inp["sd_center"], inp["sd_kp"], inp["img"], center_size=c["center_size"],
+                bbox=c["bbox"], mean=S.MEAN, std=S.STD, intermediates=inter)
+        if c.get("expect_none"):
+            assert pts is None and opts is None
+            out[tag + ".none"] = np.int64(1)
+            print(tag, "ok (None path)")
+            continue
+        must_equal(pts, opts, tag + ".points2D")
+        must_equal(conf, oconf, tag + ".confidences")
+        kh = inter["kp_heatmap"]
+        top2 = kh.flatten(2).topk(2, dim=2)[0][0]
+        margin = ((top2[:, 0] - top2[:, 1]) / top2[:, 0].abs()).min().item()
+        meta[tag] = dict(kp_argmax_margin=margin, center_hm=inter["center_hm"].tolist())
+        assert margin > 1e-3, "fragile keypoint argmax: change seed"
+        out[tag + ".points2D"] = pts.numpy()
+        out[tag + ".confidences"] = conf.numpy()
+        out[tag + ".center_hm"] = inter["center_hm"].numpy()
+        print(tag, "ok", pts[:3].tolist(), conf[:3].tolist(), "margin %.4f" % margin)
+    save("predictor2d", out)
+    with open(os.path.join(HERE, "predictor2d_meta.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
+ALL = dict(predictor2d=case_predictor2d, state_spec=case_state_spec, efficienttrack=case_efficienttrack,
            reprojection=case_reprojection, v2v=case_v2v, geometry=case_geometry,
            hybridnet=case_hybridnet, predictor=case_predictor)
 

@@ -163,3 +163,28 @@ def test_predictor3d_uint8_ingest():
     pts, conf, valid = pred.forward_batch(cuda(torch.stack([u8, u8])), *dev)
     torch.cuda.synchronize()
     assert int(valid.sum()) == 2 and (pts[1] - p0[0]).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("tag", list(cases.PREDICTOR2D_CASES))
+def test_predictor2d(tag, golden):
+    """JarvisPredictor2D.forward vs the reference's fixtures.
+    points2D is an integer path (argmax indices): bit-exact."""
+    from jarvis_hybridnet_amd.prediction.jarvis2D import JarvisPredictor2D
+    c = cases.PREDICTOR2D_CASES[tag]
+    inp = cases.predictor2d_inputs(tag)
+    cfg = make_cfg(dict(J=c["J"], bbox=c["bbox"], C=1, roi=32, spacing=2), c["center_size"])
+    pred = JarvisPredictor2D(cfg, inp["sd_center"], inp["sd_kp"])
+    pts, conf = pred(cuda(inp["img"]))
+    torch.cuda.synchronize()
+    g = golden("predictor2d")
+    if c.get("expect_none"):
+        assert pts is None and conf is None
+        return
+    assert torch.equal(pts.cpu(), torch.from_numpy(g[tag + ".points2D"]))
+    ec = max_err(conf, torch.from_numpy(g[tag + ".confidences"]))
+    report("predictor2d", tag=tag, conf=ec)
+    assert ec < 1e-5
+    # batch form: two copies of the image -> two identical rows
+    p2, c2, v2 = pred.forward_batch(cuda(torch.cat([inp["img"], inp["img"]])))
+    torch.cuda.synchronize()
+    assert int(v2.sum()) == 2 and torch.equal(p2[0], p2[1]) and torch.equal(p2[0].long().cpu(), pts.cpu())

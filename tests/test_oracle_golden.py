@@ -120,3 +120,19 @@ def test_predictor(golden, tag):
     check_summary(g, tag + ".center3d", inter["center3d"], **TOL)
     check_summary(g, tag + ".points3D", pts, **TOL)
     check_summary(g, tag + ".confidences", conf, **TOL)
+
+
+@pytest.mark.parametrize("tag", list(cases.PREDICTOR2D_CASES))
+def test_predictor2d(golden, tag):
+    c = cases.PREDICTOR2D_CASES[tag]
+    inp = cases.predictor2d_inputs(tag)
+    with torch.no_grad():
+        pts, conf = O.predictor2d_forward(inp["sd_center"], inp["sd_kp"], inp["img"],
+                                          center_size=c["center_size"], bbox=c["bbox"],
+                                          mean=S.MEAN, std=S.STD)
+    g = golden("predictor2d")
+    if c.get("expect_none"):
+        assert pts is None and conf is None
+        return
+    check_summary(g, tag + ".points2D", pts)
+    check_summary(g, tag + ".confidences", conf, **TOL)
