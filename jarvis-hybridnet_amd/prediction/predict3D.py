@@ -1,0 +1,68 @@
+"""Output side of the predict3D driver (mirrors jarvis/prediction/predict3D.py:64-70,
+87-97,141-155): `data3D.csv` rows and `info.yaml`, so that the
+reference's visualisation / analysis tools consume the results unchanged.
+
+Video decoding (cv2.VideoCapture) and project management are outside the hot path:
+`predict3D_frames` takes any iterable of decoded multi-view frame sets instead.
+"""
+import csv
+import itertools
+import os
+
+import torch
+
+
+def create_header(writer, cfg):
+    """Two header rows: every joint name four times, then x,y,z,confidence per joint."""
+    joints = list(itertools.chain.from_iterable(itertools.repeat(x, 4) for x in cfg.KEYPOINT_NAMES))
+    coords = ["x", "y", "z", "confidence"] * len(cfg.KEYPOINT_NAMES)
+    writer.writerow(joints)
+    writer.writerow(coords)
+
+
+def create_info_file(params):
+    """info.yaml with the four keys the reference writes (plain YAML mapping)."""
+    with open(os.path.join(params.output_dir, "info.yaml"), "w") as f:
+        for key in ("recording_path", "dataset_name", "frame_start", "number_frames"):
+            val = getattr(params, key)
+            f.write("%s: %s\n" % (key, "null" if val is None else val))
+
+
+def frame_row(points3D, confidences, num_joints):
+    """One CSV row: [x, y, z, confidence] per joint, or 'NaN' x 4J when the predictor
+    returned (None, None).  Same element types as the reference (Python floats from
+    `.tolist()`, numpy float32 confidences), hence the same text."""
+    if points3D is None:
+        return ["NaN"] * (num_joints * 4)
+    row = []
+    for point, conf in zip(points3D.squeeze(), confidences.squeeze().cpu().numpy()):
+        row = row + point.tolist() + [conf]
+    return row
+
+
+def predict3D_frames(predictor, frame_sets, cameraMatrices, intrinsicMatrices,
+                     distortionCoefficients, cfg, output_dir, params=None):
+    """Run `predictor` over an iterable of multi-view frame sets -- (C,H,W,3) uint8 BGR
+    arrays / tensors exactly as cv2 delivers them, or (C,3,H,W) fp32 RGB -- and write
+    data3D.csv (+ info.yaml when `params` is given).  Returns the number of frames."""
+    os.makedirs(output_dir, exist_ok=True)
+    if params is not None:
+        params.output_dir = output_dir
+        create_info_file(params)
+    n = 0
+    with open(os.path.join(output_dir, "data3D.csv"), "w", newline="") as f:
+        writer = csv.writer(f, delimiter=",", quotechar='"', quoting=csv.QUOTE_MINIMAL)
+        names = getattr(cfg, "KEYPOINT_NAMES", [])
+        if len(names) == cfg.KEYPOINTDETECT.NUM_JOINTS:
+            create_header(writer, cfg)
+        for frames in frame_sets:
+            x = torch.as_tensor(frames)
+            if x.dtype == torch.uint8:
+                pts, conf = predictor.forward_uint8(x.cuda(), cameraMatrices, intrinsicMatrices,
+                                                    distortionCoefficients)
+            else:
+                pts, conf = predictor(x.cuda(), cameraMatrices, intrinsicMatrices,
+                                      distortionCoefficients)
+            writer.writerow(frame_row(pts, conf, cfg.KEYPOINTDETECT.NUM_JOINTS))
+            n += 1
+    return n

@@ -52,6 +52,40 @@ def hybridnet_weights(model_size, num_joints, seed, deconv_std=1.2):
     return _fill(arch.hybridnet_params(model_size, num_joints), seed, deconv_std)
 
 
+def ring_cameras(num_cameras, width, height, focal=1800.0, radius=1500.0, k1=-0.05, k2=0.01):
+    """Per-camera (R (3,3), T (3,), Kt (3,3), dist (5,)) in the convention of the
+    reference's calibration files (row-vector: x_cam = X @ R + T, pixel_h = x_cam @ Kt)."""
+    cams = []
+    for i in range(num_cameras):
+        th = 2.0 * math.pi * i / num_cameras
+        ph = 0.3 * math.sin(3.0 * th)
+        pos = radius * np.array([math.cos(th) * math.cos(ph),
+                                 math.sin(th) * math.cos(ph), math.sin(ph)])
+        z = -pos / np.linalg.norm(pos)
+        x = np.cross(z, np.array([0.0, 0.0, 1.0]))
+        x /= np.linalg.norm(x)
+        y = np.cross(z, x)
+        rwc = np.stack([x, y, z], 0)
+        kt = np.array([[focal, 0, 0], [0, focal, 0], [width / 2.0, height / 2.0, 1.0]])
+        cams.append((rwc.T, -pos @ rwc.T, kt, np.array([k1, k2, 0.0, 0.0, 0.0])))
+    return cams
+
+
+def write_opencv_yaml(path, R, T, Kt, dist):
+    """One camera in the OpenCV FileStorage YAML layout the reference reads
+    (datasets/*/calib_params/*/*.yaml: intrinsicMatrix, distortionCoefficients, R, T)."""
+    def mat(name, a, rows, cols):
+        data = ", ".join(repr(float(v)) for v in np.asarray(a, dtype=np.float64).reshape(-1))
+        return "%s: !!opencv-matrix\n   rows: %d\n   cols: %d\n   dt: d\n   data: [ %s ]\n" % (
+            name, rows, cols, data)
+    with open(path, "w") as f:
+        f.write("%YAML:1.0\n---\n")
+        f.write(mat("intrinsicMatrix", Kt, 3, 3))
+        f.write(mat("distortionCoefficients", dist, 1, 5))
+        f.write(mat("R", R, 3, 3))
+        f.write(mat("T", T, 3, 1))
+
+
 def ring_calibration(num_cameras, width, height, focal=1800.0, radius=1500.0,
                      k1=-0.05, k2=0.01):
     """Cameras on a ring looking at the origin, in the reference's storage

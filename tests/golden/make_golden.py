@@ -383,7 +383,81 @@ def case_predictor2d():
         json.dump(meta, f, indent=1)
 
 
-ALL = dict(predictor2d=case_predictor2d, state_spec=case_state_spec, efficienttrack=case_efficienttrack,
+def case_calibration():
+    """Calibration files -> ReprojectionTool tensors (utils/reprojection.py:16-46,93-111).
+    cv2 is absent here, so the reference's TorchCamera.get_mat_from_file is served by an
+    independent parser (PyYAML with an !!opencv-matrix constructor); everything after
+    the file read is the reference's own code."""
+    import yaml
+    from jarvis.utils import reprojection as RP
+
+    class Loader(yaml.SafeLoader):
+        pass
+
+    def opencv_matrix(loader, node):
+        m = loader.construct_mapping(node, deep=True)
+        return np.array(m["data"], dtype=np.float64).reshape(m["rows"], m["cols"])
+    Loader.add_constructor("tag:yaml.org,2002:opencv-matrix", opencv_matrix)
+
+    def get_mat(self, filepath, node):
+        text = open(filepath).read().replace("%YAML:1.0", "%YAML 1.1", 1)
+        return yaml.load(text, Loader=Loader)[node]
+    RP.TorchCamera.get_mat_from_file = get_mat
+
+    cdir = os.path.join(HERE, "calib")
+    os.makedirs(cdir, exist_ok=True)
+    names = ["Camera_A", "Camera_B", "Camera_C", "Camera_D"]
+    for name, (Rm, T, Kt, dist) in zip(names, S.ring_cameras(4, 640, 512, 900.0)):
+        S.write_opencv_yaml(os.path.join(cdir, name + ".yaml"), Rm, T, Kt, dist)
+    tool = RP.ReprojectionTool(cdir, {n: n + ".yaml" for n in names}, "cpu")
+    out = dict(cameraMatrices=tool.cameraMatrices.numpy(),
+               intrinsicMatrices=tool.intrinsicMatrices.numpy(),
+               distortionCoefficients=tool.distortionCoefficients.numpy())
+    # the files describe the same rig as synthetic.ring_calibration
+    cam, intr, dist = S.ring_calibration(4, 640, 512, 900.0)
+    assert (tool.cameraMatrices - cam).abs().max() < 1e-2
+    if os.path.isdir("/root/reference/datasets/Example_Dataset/calib_params/12Cam_Ralph"):
+        # sanity on the reference's real 12-camera calibration (files do not travel)
+        rd = "/root/reference/datasets/Example_Dataset/calib_params/12Cam_Ralph"
+        files = sorted(f for f in os.listdir(rd) if f.endswith(".yaml"))
+        real = RP.ReprojectionTool(rd, {f[:-5]: f for f in files}, "cpu")
+        from jarvis_hybridnet_amd.utils.reprojection import ReprojectionTool as Mine
+        mine = Mine(rd, {f[:-5]: f for f in files}, "cpu")
+        for a, b in ((real.cameraMatrices, mine.cameraMatrices),
+                     (real.intrinsicMatrices, mine.intrinsicMatrices),
+                     (real.distortionCoefficients, mine.distortionCoefficients)):
+            must_equal(a, b, "real 12-camera calibration")
+        print("real 12-camera calibration: loader == reference (%d cameras)" % len(files))
+    save("calibration", out)
+
+
+def case_csv():
+    """data3D.csv wire format (prediction/predict3D.py:64-70,87-97,141-146)."""
+    import csv
+    import io
+    from jarvis.prediction.predict3D import create_header
+    g = dict(np.load(os.path.join(HERE, "predictor.npz")))
+    cfg = R.ns(KEYPOINT_NAMES=["joint%d" % i for i in range(23)])
+    buf = io.StringIO()
+    writer = csv.writer(buf, delimiter=",", quotechar='"', quoting=csv.QUOTE_MINIMAL)
+    create_header(writer, cfg)
+    pts = torch.from_numpy(g["cfg2.points3D"])
+    conf = torch.from_numpy(g["cfg2.confidences"])
+    # the reference's row loop (predict3D.py:88-97)
+    row = []
+    for point, c in zip(pts.squeeze(), conf.squeeze().cpu().numpy()):
+        row = row + point.tolist() + [c]
+    writer.writerow(row)
+    row = []
+    for i in range(23 * 4):
+        row = row + ["NaN"]
+    writer.writerow(row)
+    with open(os.path.join(HERE, "data3D_expected.csv"), "w", newline="") as f:
+        f.write(buf.getvalue())
+    print("wrote data3D_expected.csv (%d bytes)" % len(buf.getvalue()))
+
+
+ALL = dict(calibration=case_calibration, csv=case_csv, predictor2d=case_predictor2d, state_spec=case_state_spec, efficienttrack=case_efficienttrack,
            reprojection=case_reprojection, v2v=case_v2v, geometry=case_geometry,
            hybridnet=case_hybridnet, predictor=case_predictor)
 

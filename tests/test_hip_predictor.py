@@ -1,6 +1,7 @@
 """GPU: HybridNetBackbone.forward and JarvisPredictor3D.forward (HIP) against
 the CPU oracle and the reference's golden outputs, incl. the (None, None) path
 and the time-batched throughput form."""
+import os
 from types import SimpleNamespace as NS
 
 import pytest
@@ -188,3 +189,30 @@ def test_predictor2d(tag, golden):
     p2, c2, v2 = pred.forward_batch(cuda(torch.cat([inp["img"], inp["img"]])))
     torch.cuda.synchronize()
     assert int(v2.sum()) == 2 and torch.equal(p2[0], p2[1]) and torch.equal(p2[0].long().cpu(), pts.cpu())
+
+
+def test_predict3d_frames_writes_csv(tmp_path, golden):
+    """frames in (uint8 BGR as decoded, and fp32), data3D.csv out."""
+    import csv
+    from jarvis_hybridnet_amd.prediction.jarvis3D import JarvisPredictor3D
+    from jarvis_hybridnet_amd.prediction.predict3D import predict3D_frames
+    c = cases.PREDICTOR_CASES["cfg2"]
+    inp = cases.predictor_inputs("cfg2")
+    cfg = make_cfg(c, c["center_size"])
+    cfg.KEYPOINT_NAMES = ["k%d" % i for i in range(c["J"])]
+    pred = JarvisPredictor3D(cfg, inp["sd_center"], inp["sd_hybrid"])
+    u8 = (inp["imgs"].permute(0, 2, 3, 1)[..., [2, 1, 0]] * 255).round().to(torch.uint8).numpy()
+    dev = [cuda(inp[k]) for k in ("cam", "intr", "dist")]
+    n = predict3D_frames(pred, [inp["imgs"], u8, u8], *dev, cfg,
+                         str(tmp_path), NS(recording_path="r", dataset_name="d", frame_start=0,
+                                           number_frames=3))
+    rows = list(csv.reader(open(tmp_path / "data3D.csv")))
+    assert n == 3 and len(rows) == 5 and len(rows[2]) == 4 * c["J"]
+    assert rows[0][:4] == ["k0"] * 4 and rows[1][:4] == ["x", "y", "z", "confidence"]
+    gold = torch.from_numpy(golden("predictor")["cfg2.points3D"])[0]
+    got = torch.tensor([float(v) for v in rows[2]]).view(c["J"], 4)
+    assert (got[:, :3] - gold).abs().max() < 1e-3
+    got8 = torch.tensor([float(v) for v in rows[3]]).view(c["J"], 4)
+    assert (got8[:, :3] - gold).abs().max() < 20.0    # 8-bit quantised input, random-weight nets
+    assert rows[3] == rows[4]
+    assert os.path.isfile(tmp_path / "info.yaml")
