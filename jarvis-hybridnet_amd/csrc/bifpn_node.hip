@@ -48,7 +48,9 @@ __device__ __forceinline__ float4 node_fetch(const float* in, int mode, int n, i
 }
 
 __device__ __forceinline__ float node_act(float v, int act) {
-  if (act == ACT_SILU) return v / (1.f + expf(-v));
+  // SiLU with the hardware exp2 / reciprocal (about 1e-7 relative error; the prologue is
+  // instruction-bound on the IEEE expf + division otherwise)
+  if (act == ACT_SILU) return __fdividef(v, 1.f + __expf(-v));
   if (act == ACT_RELU) return fmaxf(v, 0.f);
   return v;
 }
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(512) void bifpn_node_kernel(const NodeArgs a) {
   const int Cp = a.Cp;
   const int SA = Cp + 4;                         // operand tile stride (floats)
   const int SF = a.cf + 4;                       // halo tile stride
-  float* mr_ = lds;                              // [3][Cp][2] mean, rstd
+  float* mr_ = lds;                              // [3][Cp] mean, then [3][Cp] rstd
   float* dwl = mr_ + 3 * Cp * 2;                 // [9][Cp] depthwise weights
   float* At = dwl + 9 * Cp;                      // [128][SA]
   float* Ft = At + 128 * SA;                     // [180][SF]
@@ -93,8 +95,8 @@ __global__ __launch_bounds__(512) void bifpn_node_kernel(const NodeArgs a) {
       mean = (float)mu;
       rstd = (float)(1.0 / sqrt(var + 1e-5));
     }
-    mr_[(k * Cp + c) * 2 + 0] = mean;
-    mr_[(k * Cp + c) * 2 + 1] = rstd;
+    mr_[k * Cp + c] = mean;
+    mr_[3 * Cp + k * Cp + c] = rstd;
   }
   __syncthreads();
 
@@ -129,9 +131,10 @@ __global__ __launch_bounds__(512) void bifpn_node_kernel(const NodeArgs a) {
 #pragma unroll
           for (int k = 0; k < NIN; ++k) {
             float4 x = v[u][k];
-            const float* m = mr_ + (k * Cp + c) * 2;
-            x.x = (x.x - m[0]) * m[1]; x.y = (x.y - m[2]) * m[3];
-            x.z = (x.z - m[4]) * m[5]; x.w = (x.w - m[6]) * m[7];
+            const float4 mu = *reinterpret_cast<const float4*>(mr_ + k * Cp + c);
+            const float4 rs = *reinterpret_cast<const float4*>(mr_ + 3 * Cp + k * Cp + c);
+            x.x = (x.x - mu.x) * rs.x; x.y = (x.y - mu.y) * rs.y;
+            x.z = (x.z - mu.z) * rs.z; x.w = (x.w - mu.w) * rs.w;
             const float wk = a.w[k];
             if (k == 0) {
               r = make_float4(__fmul_rn(wk, x.x), __fmul_rn(wk, x.y), __fmul_rn(wk, x.z), __fmul_rn(wk, x.w));
