@@ -141,7 +141,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   constexpr int S = KC + G::SPAD;             // LDS pixel stride in floats (even)
   constexpr int S2 = S / 2;                   // ... in float2 units
   constexpr int Q4 = KC / 4;                  // float4 per pixel and pass
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+  extern __shared__ __attribute__((aligned(16))) float lds_all[];
+  float* nrm = lds_all;                         // [cin_p] mean, [cin_p] rstd (optional)
+  float* lds = lds_all + a.nrm_floats;          // halo patch
   float2* lds2 = reinterpret_cast<float2*>(lds);
 
   const int tid = threadIdx.x;
@@ -180,6 +182,18 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  if (a.in_stats) {
+    // InstanceNorm of the input from the producer's fused statistics (biased variance)
+    for (int c = tid; c < a.cin_p; c += 256) {
+      const double* st = a.in_stats + ((size_t)(blockIdx.z / a.nphase) * a.cin_p + c) * 2;
+      const double mu = st[0] * (double)a.in_inv;
+      double var = st[1] * (double)a.in_inv - mu * mu;
+      if (var < 0.0) var = 0.0;
+      nrm[c] = (float)mu;
+      nrm[a.cin_p + c] = (float)(1.0 / sqrt(var + 1e-5));
+    }
+  }
+
   const float* __restrict__ xin = a.x + (size_t)n * a.Din * a.Hin * a.Win * a.cin_p;
   const int nkc8_total = a.cin_p >> 3;
   const int nb16_total = a.cout_p16 >> 4;
@@ -207,6 +221,18 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
       if (c < a.cin_p && iz >= 0 && iz < a.Din && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) {
         v = *reinterpret_cast<const float4*>(
             xin + ((size_t)(iz * a.Hin + iy) * a.Win + ix) * a.cin_p + c);
+        if (a.in_stats) {
+          const float4 mu = *reinterpret_cast<const float4*>(nrm + c);
+          const float4 rs = *reinterpret_cast<const float4*>(nrm + a.cin_p + c);
+          v.x = (v.x - mu.x) * rs.x; v.y = (v.y - mu.y) * rs.y;
+          v.z = (v.z - mu.z) * rs.z; v.w = (v.w - mu.w) * rs.w;
+          if (a.in_act == ACT_RELU) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+          } else if (a.in_act == ACT_SILU) {
+            v.x = __fdividef(v.x, 1.f + __expf(-v.x)); v.y = __fdividef(v.y, 1.f + __expf(-v.y));
+            v.z = __fdividef(v.z, 1.f + __expf(-v.z)); v.w = __fdividef(v.w, 1.f + __expf(-v.w));
+          }
+        }
         if (a.gate) {
           const float4 g = *reinterpret_cast<const float4*>(a.gate + (size_t)n * a.cin_p + c);
           v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w;
@@ -299,6 +325,7 @@ int launch_conv_inst(const ConvArgs& b, dim3 grid, hipStream_t s) {
   size_t lds = G::lds_bytes(KC8V * 8);
   const size_t red = (size_t)4 * 4 * 16 * 2 * sizeof(float);
   if (lds < red) lds = red;
+  lds += (size_t)b.nrm_floats * sizeof(float);
   JH_REQUIRE(lds <= 160 * 1024, "conv patch does not fit LDS");
   auto kern = conv_mfma_kernel<ND, K, STRIDE, TZ, TY, TX, NRV, KC8V>;
   static bool big_lds_enabled = false;

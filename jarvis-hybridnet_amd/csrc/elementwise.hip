@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(
         const float4 a = *reinterpret_cast<const float4*>(r2 + off);
         v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
       }
-      *reinterpret_cast<float4*>(y + off) = v;
+      if (y) *reinterpret_cast<float4*>(y + off) = v;     // y == nullptr: pooled sums only
       ps.x += v.x; ps.y += v.y; ps.z += v.z; ps.w += v.w;
     }
   }

@@ -96,6 +96,10 @@ struct ConvArgs {
   const float* w;        // packed weights
   const float* bias;     // [cout_p16] or nullptr
   const float* gate;     // [N][cin_p] multiplicative gate on the input or nullptr
+  const double* in_stats;  // [N][cin_p][2]: InstanceNorm (+ in_act) applied to the input on load
+  float in_inv;            // 1 / pixels the input statistics were taken over
+  int in_act;
+  int nrm_floats;          // LDS floats reserved in front of the patch for mean / rstd
   double* stats;         // [N][cout_p][2] (sum, sumsq) accumulated, or nullptr
   int N, Din, Hin, Win, cin_p;
   int Dout, Hout, Wout;  // logical conv output extent of ONE phase
@@ -113,8 +117,15 @@ int pack_conv_weights(const ConvDesc& d, const float* w_host, const float* b_hos
                       bool transposed, ConvWeights* out);
 void free_conv_weights(ConvWeights* w);
 
+// InstanceNorm (+ activation) of the conv INPUT, applied while the patch is staged: the
+// producer's raw output and fused statistics are consumed directly, no normalised copy.
+struct InNorm {
+  const double* stats = nullptr;
+  float inv = 0.f;
+  int act = 0;
+};
 int launch_conv(const ConvDesc& d, const ConvWeights& w, const Act& x, const Act& y,
-                const float* gate, double* stats, hipStream_t s);
+                const float* gate, double* stats, hipStream_t s, const InNorm* in = nullptr);
 // output extent of a conv described by d for an input of extent (D,H,W)
 void conv_out_shape(const ConvDesc& d, int D, int H, int W, int* Do, int* Ho, int* Wo);
 

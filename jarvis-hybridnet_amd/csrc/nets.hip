@@ -93,7 +93,8 @@ int Plan::get(const ParamMap& pm, const std::string& key, size_t numel, const fl
 
 int Plan::add_conv(const ParamMap& pm, const ConvDesc& d, const std::string& wkey,
                    const std::string& bkey, bool transposed, const Act& x, const Act& y,
-                   const float* gate, bool want_stats, size_t* stats_off) {
+                   const float* gate, bool want_stats, size_t* stats_off, long in_stats_off,
+                   float in_inv, int in_act) {
   size_t taps;
   if (d.ostride > 1) taps = (d.nd == 2) ? 16 : 8;
   else taps = (size_t)d.k * d.k * (d.nd == 3 ? d.k : 1);
@@ -118,8 +119,11 @@ int Plan::add_conv(const ParamMap& pm, const ConvDesc& d, const std::string& wke
   char nm[96];
   snprintf(nm, sizeof nm, "conv%dd_k%ds%d%s_%dx%d@%d", d.nd, d.ostride > 1 ? (d.nd == 2 ? 4 : 2) : d.k,
            d.ostride > 1 ? 2 : d.stride, d.ostride > 1 ? "T" : "", d.cin, d.cout, y.W);
-  push(nm, flops, bytes, [this, d, cw, x, y, gate, want_stats, off](hipStream_t s) {
-    return launch_conv(d, cw, x, y, gate, want_stats ? sc(off) : nullptr, s);
+  push(nm, flops, bytes,
+       [this, d, cw, x, y, gate, want_stats, off, in_stats_off, in_inv, in_act](hipStream_t s) {
+    InNorm in;
+    if (in_stats_off >= 0) { in.stats = sc((size_t)in_stats_off); in.inv = in_inv; in.act = in_act; }
+    return launch_conv(d, cw, x, y, gate, want_stats ? sc(off) : nullptr, s, &in);
   });
   return 0;
 }
@@ -213,9 +217,11 @@ int EffTrackPlan::mbconv(const ParamMap& pm, const std::string& p, int stage, in
       return launch_depthwise(e, wd, k, raw.p, sc(st1), s);
     });
   }
-  // _gn1 + swish, pooled for squeeze-excite (in place)
+  // _gn1 + swish: only its per-(n,c) pooled sums (squeeze-excite) are computed here; the
+  // normalised tensor itself is never written -- the project conv re-applies
+  // InstanceNorm + SiLU (+ the SE gate) while it stages its operand
   const size_t pool = scratch((size_t)raw.N * raw.Cp);
-  add_norm(raw, st1, ACT_SILU, nullptr, nullptr, raw.p, (long)pool);
+  add_norm(raw, st1, ACT_SILU, nullptr, nullptr, nullptr, (long)pool);
   // squeeze-excite gate
   const float *wr, *br, *we, *be;
   if (get(pm, p + "_se_reduce.weight", (size_t)squeeze * mid, &wr)) return 1;
@@ -237,7 +243,7 @@ int EffTrackPlan::mbconv(const ParamMap& pm, const std::string& p, int stage, in
   if (new_act(x.N, 1, Ho, Wo, cout, out)) return 1;
   size_t st2 = 0;
   if (add_conv(pm, conv_desc(2, 1, 1, 0, mid, cout), p + "_project_conv.weight", "", false, raw,
-               *out, gate, true, &st2)) return 1;
+               *out, gate, true, &st2, (long)st1, 1.f / (float)(Ho * Wo), ACT_SILU)) return 1;
   const bool skip = (stride == 1 && cin == cout);
   add_norm(*out, st2, ACT_NONE, skip ? x.p : nullptr, nullptr, out->p, -1);
   return 0;
@@ -424,10 +430,11 @@ int V2VPlan::res_block(const ParamMap& pm, const std::string& p, int c, const Ac
   size_t s1 = 0, s2 = 0;
   if (add_conv(pm, conv_desc(3, 3, 1, 1, c, c), p + "res_branch.0.weight", p + "res_branch.0.bias",
                false, x, a, nullptr, true, &s1)) return 1;
-  add_norm(a, s1, ACT_RELU, nullptr, nullptr, a.p, -1);
+  // the InstanceNorm + ReLU between the two convs is applied by the second conv on load
   if (new_act(x.N, x.D, x.H, x.W, c, out)) return 1;
   if (add_conv(pm, conv_desc(3, 3, 1, 1, c, c), p + "res_branch.3.weight", p + "res_branch.3.bias",
-               false, a, *out, nullptr, true, &s2)) return 1;
+               false, a, *out, nullptr, true, &s2, (long)s1, 1.f / (float)(x.D * x.H * x.W),
+               ACT_RELU)) return 1;
   add_norm(*out, s2, ACT_RELU, x.p, extra, out->p, -1);
   return 0;
 }
