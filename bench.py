@@ -158,6 +158,7 @@ def main():
         dt = tt.item()
     res = step()
     torch.cuda.synchronize()
+    res = [r.clone() if torch.is_tensor(r) else r for r in res]      # `out` is reused below
     valid = int(res[2].sum().item())
     fps = T * n_groups * args.steps / dt
 
