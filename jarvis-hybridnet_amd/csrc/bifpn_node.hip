@@ -75,8 +75,9 @@ __global__ __launch_bounds__(512) void bifpn_node_kernel(const NodeArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6, mrow = lane & 15, kq = lane >> 4;
   const int tiles_x = (a.W + kNodeTX - 1) / kNodeTX;
-  const int tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
-  const int n = blockIdx.y;
+  const BlockId bid = xcd_block();
+  const int tile_x = bid.x % tiles_x, tile_y = bid.x / tiles_x;
+  const int n = bid.y;
   const int oy0 = tile_y * kNodeTY, ox0 = tile_x * kNodeTX;
 
   const int nk8 = Cp >> 3, nb = a.cout_p16 >> 4;

@@ -155,13 +155,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   // ---- block coordinates
   const int tiles_x = (a.Wout + TX - 1) / TX;
   const int tiles_y = (a.Hout + TY - 1) / TY;
-  int t = blockIdx.x;
+  const BlockId bid = xcd_block();             // neighbouring tiles share an XCD's L2
+  int t = bid.x;
   const int tile_x = t % tiles_x; t /= tiles_x;
   const int tile_y = t % tiles_y; t /= tiles_y;
   const int tile_z = t;
-  const int nb0 = blockIdx.y * NR;
-  const int n = blockIdx.z / a.nphase;
-  const int ph = blockIdx.z % a.nphase;
+  const int nb0 = bid.y * NR;
+  const int n = bid.z / a.nphase;
+  const int ph = bid.z % a.nphase;
   const int oz0 = tile_z * TZ, oy0 = tile_y * TY, ox0 = tile_x * TX;
   const int iz0 = oz0 * STRIDE - a.phase[ph].pad[0];
   const int iy0 = oy0 * STRIDE - a.phase[ph].pad[1];
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   if (a.in_stats) {
     // InstanceNorm of the input from the producer's fused statistics (biased variance)
     for (int c = tid; c < a.cin_p; c += 256) {
-      const double* st = a.in_stats + ((size_t)(blockIdx.z / a.nphase) * a.cin_p + c) * 2;
+      const double* st = a.in_stats + ((size_t)n * a.cin_p + c) * 2;
       const double mu = st[0] * (double)a.in_inv;
       double var = st[1] * (double)a.in_inv - mu * mu;
       if (var < 0.0) var = 0.0;

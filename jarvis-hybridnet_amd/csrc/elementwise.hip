@@ -171,9 +171,10 @@ __global__ __launch_bounds__(256) void depthwise_lds_kernel(
   extern __shared__ __attribute__((aligned(16))) float sm[];     // [HT*HT][SP]
   const int tid = threadIdx.x;
   const int tiles_x = (W + T - 1) / T;
-  const int ox0 = (blockIdx.x % tiles_x) * T, oy0 = (blockIdx.x / tiles_x) * T;
-  const int c0 = blockIdx.y * CC;
-  const int n = blockIdx.z;
+  const BlockId bid = xcd_block();
+  const int ox0 = (bid.x % tiles_x) * T, oy0 = (bid.x / tiles_x) * T;
+  const int c0 = bid.y * CC;
+  const int n = bid.z;
   const int q = min(CC, Cp - c0) >> 2;             // channel quads in this chunk (<= 8)
   const float* xin = x + (size_t)n * H * W * Cp;
   for (int idx = tid; idx < HT * HT * q; idx += 256) {

@@ -159,6 +159,29 @@ int launch_fuse(const FuseArgs& f, const Act& out, hipStream_t s);
 int launch_maxpool2(const Act& x, float* y, hipStream_t s);
 
 // fused BiFPN node (csrc/bifpn_node.hip)
+// XCD-aware block order.  The dispatcher places linear block b on XCD b % 8 (observed, not
+// a contract: used for speed only), so neighbouring blocks -- which share halo pixels --
+// land on 8 different, mutually non-coherent L2s and every halo is fetched from the fabric
+// again.  This bijection of [0, total) hands each XCD one CONTIGUOUS range of logical
+// blocks instead: XCD x runs logical blocks [start(x), start(x) + count(x)).
+struct BlockId { unsigned x, y, z; };
+#if defined(__HIPCC__)
+__device__ __forceinline__ unsigned xcd_linear(unsigned L, unsigned total) {
+  const unsigned q = total >> 3, r = total & 7u, x = L & 7u, s = L >> 3;
+  return x < r ? x * (q + 1) + s : r * (q + 1) + (x - r) * q + s;
+}
+__device__ __forceinline__ BlockId xcd_block() {
+  const unsigned gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+  const unsigned L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+  unsigned l = xcd_linear(L, gx * gy * gz);
+  BlockId b;
+  b.x = l % gx; l /= gx;
+  b.y = l % gy;
+  b.z = l / gy;
+  return b;
+}
+#endif
+
 struct NodeArgs;
 int launch_bifpn_node(const NodeArgs& a, hipStream_t s);
 

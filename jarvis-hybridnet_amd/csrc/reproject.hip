@@ -114,15 +114,16 @@ __global__ __launch_bounds__(256) void repro_gather_kernel(
     int* __restrict__ idx_out, int C, int G, int hs, int Jp, int heat_pad, int div255, int ci_n,
     int cj_n) {
   extern __shared__ __attribute__((aligned(16))) float2 ctab[];   // [C][ci_n][cj_n][Gh]
-  const int t = blockIdx.y;
+  const BlockId bid = xcd_block();             // consecutive planes share heatmap regions
+  const int t = bid.y;
   const int Gh = G >> 1;
   const int nvox = G * G * G, nvox_c = Gh * Gh * Gh;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   // blocks never straddle an i-plane: plane p owns blocks [p*bpp, (p+1)*bpp)
   const int bpp = (G * G + 255) / 256;
-  const int plane = blockIdx.x / bpp;
-  const int vox0 = plane * G * G + (blockIdx.x % bpp) * 256;
+  const int plane = bid.x / bpp;
+  const int vox0 = plane * G * G + (bid.x % bpp) * 256;
   const int vox_end = (plane + 1) * G * G;
   const int wave_vox0 = vox0 + (tid >> 6) * 64;
   const int vox = wave_vox0 + lane;

@@ -41,28 +41,56 @@ def frame_row(points3D, confidences, num_joints):
 
 
 def predict3D_frames(predictor, frame_sets, cameraMatrices, intrinsicMatrices,
-                     distortionCoefficients, cfg, output_dir, params=None):
+                     distortionCoefficients, cfg, output_dir, params=None, time_batch=1):
     """Run `predictor` over an iterable of multi-view frame sets -- (C,H,W,3) uint8 BGR
     arrays / tensors exactly as cv2 delivers them, or (C,3,H,W) fp32 RGB -- and write
-    data3D.csv (+ info.yaml when `params` is given).  Returns the number of frames."""
+    data3D.csv (+ info.yaml when `params` is given).  Returns the number of frames.
+
+    time_batch > 1 groups that many consecutive frame sets into one launch sequence
+    (`forward_batch`, the throughput form the bench measures); rows are written in frame
+    order and are the same as with time_batch = 1.  A short last group is padded with
+    its last frame set and the padding rows are dropped."""
     os.makedirs(output_dir, exist_ok=True)
     if params is not None:
         params.output_dir = output_dir
         create_info_file(params)
+    J = cfg.KEYPOINTDETECT.NUM_JOINTS
+    calib = (cameraMatrices, intrinsicMatrices, distortionCoefficients)
     n = 0
     with open(os.path.join(output_dir, "data3D.csv"), "w", newline="") as f:
         writer = csv.writer(f, delimiter=",", quotechar='"', quoting=csv.QUOTE_MINIMAL)
         names = getattr(cfg, "KEYPOINT_NAMES", [])
-        if len(names) == cfg.KEYPOINTDETECT.NUM_JOINTS:
+        if len(names) == J:
             create_header(writer, cfg)
+
+        def flush(group):
+            real = len(group)
+            group = group + [group[-1]] * (time_batch - real)
+            pts, conf, valid = predictor.forward_batch(torch.stack(group).cuda(), *calib)
+            pts, conf, valid = pts.cpu(), conf.cpu(), valid.cpu()
+            for t in range(real):
+                ok = int(valid[t]) != 0
+                writer.writerow(frame_row(pts[t] if ok else None, conf[t] if ok else None, J))
+            return real
+
+        group = []
         for frames in frame_sets:
             x = torch.as_tensor(frames)
+            if time_batch > 1:
+                if group and (x.dtype != group[0].dtype or x.shape != group[0].shape):
+                    n += flush(group)
+                    group = []
+                group.append(x)
+                if len(group) == time_batch:
+                    n += flush(group)
+                    group = []
+                continue
             if x.dtype == torch.uint8:
-                pts, conf = predictor.forward_uint8(x.cuda(), cameraMatrices, intrinsicMatrices,
-                                                    distortionCoefficients)
+                pts, conf = predictor.forward_uint8(x.cuda(), *calib)
             else:
-                pts, conf = predictor(x.cuda(), cameraMatrices, intrinsicMatrices,
-                                      distortionCoefficients)
-            writer.writerow(frame_row(pts, conf, cfg.KEYPOINTDETECT.NUM_JOINTS))
+                pts, conf = predictor(x.cuda(), *calib)
+            writer.writerow(frame_row(pts, conf, J))
             n += 1
+        if group:
+            n += flush(group)
     return n

@@ -216,3 +216,7 @@ def test_predict3d_frames_writes_csv(tmp_path, golden):
     assert (got8[:, :3] - gold).abs().max() < 20.0    # 8-bit quantised input, random-weight nets
     assert rows[3] == rows[4]
     assert os.path.isfile(tmp_path / "info.yaml")
+    # throughput form: groups of 2 frame sets per launch sequence (short last group padded)
+    n = predict3D_frames(pred, [u8, u8, u8], *dev, cfg, str(tmp_path / "tb"), time_batch=2)
+    rows2 = list(csv.reader(open(tmp_path / "tb" / "data3D.csv")))
+    assert n == 3 and len(rows2) == 5 and rows2[2] == rows2[3] == rows2[4] == rows[3]
