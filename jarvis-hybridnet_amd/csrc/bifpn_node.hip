@@ -17,6 +17,7 @@
 //      depthwise 3x3 from F -> LDS operand tile A[128][Cp + 4]
 //   3. MFMA 16x16x4 fp32 over K = Cp for 4 output-channel blocks at a time
 //      (weights streamed from L2 in packed B-operand order), shared epilogue.
+#include <algorithm>
 #include <cstdlib>
 #include "conv_mfma.h"
 #include "bifpn_node.h"
@@ -66,12 +67,16 @@ __global__ __launch_bounds__(512) void bifpn_node_kernel(const NodeArgs a) {
   constexpr int NT = 512;                        // threads (8 waves: latency-bound prologue)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int Cp = a.Cp;
-  const int SA = Cp + 4;                         // operand tile stride (floats)
-  const int SF = a.cf + 4;                       // halo tile stride
+  const int SA = Cp + 4;                         // operand tile stride (floats): b64 reads conflict-free
+  const int SF = a.cf;                           // halo tile stride: unpadded, so that consecutive
+                                                 // lanes touch consecutive 16-byte words
   float* mr_ = lds;                              // [3][Cp] mean, then [3][Cp] rstd
   float* dwl = mr_ + 3 * Cp * 2;                 // [9][Cp] depthwise weights
-  float* At = dwl + 9 * Cp;                      // [128][SA]
-  float* Ft = At + 128 * SA;                     // [180][SF]
+  float* Ft = dwl + 9 * Cp;                      // [180][SF]
+  // With a single channel chunk the operand tile is built in registers and then written
+  // OVER the halo tile (a.alias): 44 KB instead of 77 KB of LDS, 3 workgroups per CU.
+  float* At = a.alias ? Ft : Ft + kNodePY * kNodePX * SF;      // [128][SA]
+  float* red = a.alias ? At + 128 * SA : Ft;     // epilogue reduction scratch
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6, mrow = lane & 15, kq = lane >> 4;
   const int tiles_x = (a.W + kNodeTX - 1) / kNodeTX;
@@ -82,9 +87,9 @@ __global__ __launch_bounds__(512) void bifpn_node_kernel(const NodeArgs a) {
 
   const int nk8 = Cp >> 3, nb = a.cout_p16 >> 4;
   const float2* wl = reinterpret_cast<const float2*>(a.pw) + lane;
-  for (int i = tid; i < 9 * Cp; i += NT) dwl[i] = a.dw[i];
 
-  // 1. statistics -> mean / rstd (biased variance, eps 1e-5) of every normalised input
+  // 1. depthwise weights and statistics -> mean / rstd (biased variance, eps 1e-5)
+  for (int i = tid; i < 9 * Cp; i += NT) dwl[i] = a.dw[i];
   for (int i = tid; i < a.n_in * Cp; i += NT) {
     const int k = i / Cp, c = i % Cp;
     float mean = 0.f, rstd = 1.f;
@@ -106,7 +111,8 @@ __global__ __launch_bounds__(512) void bifpn_node_kernel(const NodeArgs a) {
     const int cw = min(a.cf, Cp - cf0);          // multiple of 4
     const int q = cw >> 2;
     const int total = kNodePY * kNodePX * q;
-    for (int base = tid; base < total; base += NT * U) {
+    for (int b0 = 0; b0 < total; b0 += NT * U) {
+      const int base = b0 + tid;
       float4 v[U][NIN];
       bool ok[U];
 #pragma unroll
@@ -153,20 +159,30 @@ __global__ __launch_bounds__(512) void bifpn_node_kernel(const NodeArgs a) {
       }
     }
     __syncthreads();
-    for (int idx = tid; idx < ((a.abl & 2) ? 0 : 128 * q); idx += NT) {
-      const int c4 = idx % q, p = idx / q;
+    // depthwise 3x3, two output rows (32 pixels x q channel quads <= 512 items) per round.
+    // When the operand tile aliases the halo tile the rounds are what makes that legal:
+    // operand rows <= 2r+1 (stride SA <= 18 * SF / 16 floats) only overwrite halo rows
+    // <= 2r+1, which no later round reads; the barrier orders this round's reads
+    // before its writes.
+    const int ditems = (a.abl & 2) ? 0 : 32 * q;
+#pragma unroll 1
+    for (int r = 0; r < kNodeTY / 2; ++r) {
+      float4 dacc = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int c4 = tid % q, p = r * 32 + tid / q;
       const int tx = p % kNodeTX, ty = p / kNodeTX;
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (tid < ditems) {
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy)
+        for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          const float4 v = *reinterpret_cast<const float4*>(Ft + ((ty + dy) * kNodePX + tx + dx) * SF + c4 * 4);
-          const float4 k = *reinterpret_cast<const float4*>(dwl + (dy * 3 + dx) * Cp + cf0 + c4 * 4);
-          acc.x = fmaf(v.x, k.x, acc.x); acc.y = fmaf(v.y, k.y, acc.y);
-          acc.z = fmaf(v.z, k.z, acc.z); acc.w = fmaf(v.w, k.w, acc.w);
-        }
-      *reinterpret_cast<float4*>(At + p * SA + cf0 + c4 * 4) = acc;
+          for (int dx = 0; dx < 3; ++dx) {
+            const float4 v = *reinterpret_cast<const float4*>(Ft + ((ty + dy) * kNodePX + tx + dx) * SF + c4 * 4);
+            const float4 k = *reinterpret_cast<const float4*>(dwl + (dy * 3 + dx) * Cp + cf0 + c4 * 4);
+            dacc.x = fmaf(v.x, k.x, dacc.x); dacc.y = fmaf(v.y, k.y, dacc.y);
+            dacc.z = fmaf(v.z, k.z, dacc.z); dacc.w = fmaf(v.w, k.w, dacc.w);
+          }
+      }
+      if (a.alias) __syncthreads();
+      if (tid < ditems) *reinterpret_cast<float4*>(At + p * SA + cf0 + c4 * 4) = dacc;
     }
     __syncthreads();
   }
@@ -208,8 +224,8 @@ __global__ __launch_bounds__(512) void bifpn_node_kernel(const NodeArgs a) {
       for (int nr = 0; nr < kNodeNRG; ++nr)
         acc[0][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac.y, bc[nr].y, acc[0][nr], 0, 0, 0);
     }
-    __syncthreads();          // Ft is reused as the reduction scratch of the epilogue
-    if (!(a.abl & 8)) conv_epilogue<1, kNodeNRG, kNodeTY, kNodeTX, 8>(acc, e, Ft, nb0, 0, oy0, ox0, tid);
+    __syncthreads();          // the scratch may be the (dead) halo tile
+    if (!(a.abl & 8)) conv_epilogue<1, kNodeNRG, kNodeTY, kNodeTX, 8>(acc, e, red, nb0, 0, oy0, ox0, tid);
     __syncthreads();
   }
 }
@@ -232,19 +248,29 @@ static int launch_node_variant(const NodeArgs& a, size_t lds, hipStream_t s) {
 int launch_bifpn_node(const NodeArgs& args, hipStream_t s) {
   NodeArgs a = args;
   if (const char* e = getenv("JH_NODE_ABL")) a.abl = atoi(e);   // timing experiments only
-  // halo chunk: as many channels as keep the whole workgroup under the LDS budget
-  // (3 workgroups per CU for the 56-channel pyramid of the small model)
-  const size_t fixed = ((size_t)3 * a.Cp * 2 + (size_t)9 * a.Cp + (size_t)128 * (a.Cp + 4)) * sizeof(float);
-  size_t budget = 78 * 1024;
-  if (const char* e = getenv("JH_NODE_LDS_KB")) budget = (size_t)atoi(e) * 1024;
-  if (fixed + (size_t)kNodePY * kNodePX * 12 * sizeof(float) > budget) budget = 78 * 1024;
-  if (fixed + (size_t)kNodePY * kNodePX * 12 * sizeof(float) > budget) budget = 156 * 1024;
-  int cf = a.Cp;
-  while (cf > 8 && fixed + (size_t)kNodePY * kNodePX * (cf + 4) * sizeof(float) > budget) cf -= 4;
-  a.cf = cf;
-  const size_t lds = fixed + (size_t)kNodePY * kNodePX * (cf + 4) * sizeof(float);
+  const size_t head = ((size_t)3 * a.Cp * 2 + (size_t)9 * a.Cp) * sizeof(float);
+  const size_t at_bytes = (size_t)128 * (a.Cp + 4) * sizeof(float);
   const size_t red = (size_t)8 * kNodeNRG * 16 * 2 * sizeof(float);
-  JH_REQUIRE((size_t)kNodePY * kNodePX * (cf + 4) * sizeof(float) >= red, "halo chunk too small");
+  const size_t halo_px = (size_t)kNodePY * kNodePX * sizeof(float);
+  // preferred: the whole channel range in one halo chunk, operand tile aliased onto it
+  // (3 workgroups per CU for the 56-channel pyramid of the small model)
+  size_t lds = head + std::max(halo_px * a.Cp, at_bytes + red);
+  a.cf = a.Cp;
+  a.alias = 1;
+  const char* na = getenv("JH_NODE_NOALIAS");
+  if (a.Cp > 64 || a.Cp < 32 || lds > 54 * 1024 || (na && atoi(na))) {
+    // fallback: separate operand tile, halo chunked to the LDS budget
+    a.alias = 0;
+    size_t budget = 78 * 1024;
+    if (const char* e = getenv("JH_NODE_LDS_KB")) budget = (size_t)atoi(e) * 1024;
+    const size_t fixed = head + at_bytes;
+    if (fixed + halo_px * 12 > budget) budget = 156 * 1024;
+    int cf = std::min(a.Cp, 64);          // the depthwise rounds handle <= 16 channel quads
+    while (cf > 8 && fixed + halo_px * cf > budget) cf -= 4;
+    a.cf = cf;
+    lds = fixed + halo_px * cf;
+    JH_REQUIRE(halo_px * cf >= red, "halo chunk too small");
+  }
   JH_REQUIRE(lds <= 160 * 1024, "BiFPN node does not fit LDS");
   const int m0 = a.mode[0], m1 = a.mode[1], m2 = a.mode[2];
   JH_REQUIRE(m0 == FUSE_SAME, "first input of a node is at the node's own level");
