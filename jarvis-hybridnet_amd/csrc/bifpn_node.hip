@@ -62,8 +62,10 @@ __device__ __forceinline__ float node_act(float v, int act) {
 template <int NIN, int M0, int M1, int M2>
 __global__ __launch_bounds__(512) void bifpn_node_kernel(const NodeArgs a) {
   constexpr int kModes[3] = {M0, M1, M2};
-  constexpr int U = 5;                           // items in flight per thread: 512 x 5 covers a
-                                                 // whole 56-channel halo tile in one round trip
+  // items in flight per thread: 512 x 5 covers a whole 56-channel halo tile in one round
+  // trip; with three inputs that costs > 80 VGPRs, i.e. the third workgroup per CU, which
+  // is worth more than the single round trip
+  constexpr int U = NIN == 3 ? 3 : 5;
   constexpr int NT = 512;                        // threads (8 waves: latency-bound prologue)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int Cp = a.Cp;
