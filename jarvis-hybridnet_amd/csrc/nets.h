@@ -84,6 +84,7 @@ struct Ref {
   Act a;
   long st = -1;
   float inv = 0.f;       // 1 / pixels the statistics were accumulated over
+  int act = 0;           // activation that follows that InstanceNorm (ACT_*)
 };
 
 class EffTrackPlan : public Plan {
@@ -96,8 +97,9 @@ class EffTrackPlan : public Plan {
 
  private:
   int mbconv(const ParamMap& pm, const std::string& p, int stage, int k, int stride, int cin,
-             int cout, int expand, const Act& x, Act* out);
-  int lateral(const ParamMap& pm, const std::string& p, int cout, const Act& x, Ref* out);
+             int cout, int expand, Ref* x, Ref* out);
+  void materialise(Ref* x);
+  int lateral(const ParamMap& pm, const std::string& p, int cout, const Ref& x, Ref* out);
   int pool(const Ref& x, Ref* out);
   int node(const ParamMap& pm, const std::string& conv_prefix, int n_in, const Ref* ins,
            const int* modes, const float* w, int act, const Act& like, int cout, Ref* out);

@@ -184,8 +184,26 @@ void fuse_weights(const float* p, int n, float* w) {
 }  // namespace
 
 // MBConvBlock.forward, efficientnet.py:90-123
+// Write IN(+act) of a "raw + statistics" tensor in place, for consumers that cannot apply
+// it on load (depthwise kernels, residual adds).
+void EffTrackPlan::materialise(Ref* x) {
+  if (x->st < 0) return;
+  add_norm(x->a, (size_t)x->st, x->act, nullptr, nullptr, x->a.p, -1);
+  x->st = -1;
+}
+
+// The input may still be "raw + statistics" (stem, or a block without a skip connection):
+// the block's first dense conv then applies that InstanceNorm(+act) while it stages its
+// operand.  The output is returned the same way when the block has no skip connection.
 int EffTrackPlan::mbconv(const ParamMap& pm, const std::string& p, int stage, int k, int stride,
-                         int cin, int cout, int expand, const Act& x, Act* out) {
+                         int cin, int cout, int expand, Ref* xin, Ref* outr) {
+  const bool skip = (stride == 1 && cin == cout);
+  // (in place: the caller's Ref is updated so that later readers of the same tensor,
+  // e.g. the BiFPN laterals, do not normalise it a second time)
+  if (skip || (stage >= 4 && expand == 1)) materialise(xin);
+  const Ref xr = *xin;
+  const Act& x = xr.a;
+  Act* out = &outr->a;
   const int mid = cin * expand;
   const int squeeze = std::max(1, (int)(cin * 0.25));
   const int Ho = (x.H + 2 * (k / 2) - k) / stride + 1, Wo = (x.W + 2 * (k / 2) - k) / stride + 1;
@@ -195,13 +213,13 @@ int EffTrackPlan::mbconv(const ParamMap& pm, const std::string& p, int stage, in
   if (stage < 4) {
     // "fused" path: one dense k x k conv; _expand_conv is never executed
     if (add_conv(pm, conv_desc(2, k, stride, k / 2, cin, mid), p + "_depthwise_conv.weight", "",
-                 false, x, raw, nullptr, true, &st1)) return 1;
+                 false, x, raw, nullptr, true, &st1, xr.st, xr.inv, xr.act)) return 1;
   } else {
     Act e = x;
     if (expand != 1) {
       if (new_act(x.N, 1, x.H, x.W, mid, &e)) return 1;
       if (add_conv(pm, conv_desc(2, 1, 1, 0, cin, mid), p + "_expand_conv.weight", "", false, x, e,
-                   nullptr, false, nullptr)) return 1;
+                   nullptr, false, nullptr, xr.st, xr.inv, xr.act)) return 1;
     }
     JH_REQUIRE(stride == 1, "depthwise stages are stride 1");
     const float* w = nullptr;
@@ -244,19 +262,26 @@ int EffTrackPlan::mbconv(const ParamMap& pm, const std::string& p, int stage, in
   size_t st2 = 0;
   if (add_conv(pm, conv_desc(2, 1, 1, 0, mid, cout), p + "_project_conv.weight", "", false, raw,
                *out, gate, true, &st2, (long)st1, 1.f / (float)(Ho * Wo), ACT_SILU)) return 1;
-  const bool skip = (stride == 1 && cin == cout);
-  add_norm(*out, st2, ACT_NONE, skip ? x.p : nullptr, nullptr, out->p, -1);
+  if (skip) {
+    add_norm(*out, st2, ACT_NONE, x.p, nullptr, out->p, -1);
+    outr->st = -1;
+  } else {                                  // _gn2 is applied by the consumers on load
+    outr->st = (long)st2;
+    outr->inv = 1.f / (float)(Ho * Wo);
+    outr->act = ACT_NONE;
+  }
   return 0;
 }
 
 // 1x1 conv + bias; its InstanceNorm (model.py:404-425) is applied by the consumers
 // from the fused statistics
-int EffTrackPlan::lateral(const ParamMap& pm, const std::string& p, int cout, const Act& x,
+int EffTrackPlan::lateral(const ParamMap& pm, const std::string& p, int cout, const Ref& xr,
                           Ref* out) {
+  const Act& x = xr.a;
   if (new_act(x.N, 1, x.H, x.W, cout, &out->a)) return 1;
   size_t st = 0;
   if (add_conv(pm, conv_desc(2, 1, 1, 0, x.C, cout), p + ".0.weight", p + ".0.bias", false, x,
-               out->a, nullptr, true, &st)) return 1;
+               out->a, nullptr, true, &st, xr.st, xr.inv, xr.act)) return 1;
   out->st = (long)st;
   out->inv = 1.f / (float)(x.H * x.W);
   return 0;
@@ -339,24 +364,28 @@ int EffTrackPlan::build(const ParamMap& pm, const std::string& pre, int size, in
 
   if (new_act(N, 1, H, W, 3, &input)) return 1;
   // stem conv + IN + swish (efficientnet.py:150-152, model.py:536-538)
-  Act x;
-  if (new_act(N, 1, H / 2, W / 2, stem, &x)) return 1;
+  Ref x;
+  if (new_act(N, 1, H / 2, W / 2, stem, &x.a)) return 1;
   size_t st = 0;
   const std::string bb = pre + "backbone_net.model.";
-  if (add_conv(pm, conv_desc(2, 3, 2, 1, 3, stem), bb + "_conv_stem.weight", "", false, input, x,
+  if (add_conv(pm, conv_desc(2, 3, 2, 1, 3, stem), bb + "_conv_stem.weight", "", false, input, x.a,
                nullptr, true, &st)) return 1;
-  add_norm(x, st, ACT_SILU, nullptr, nullptr, x.p, -1);
-  Act feats[3];
-  int nf = 0;
+  // the stem's InstanceNorm + swish is applied by the first block's conv on load
+  x.st = (long)st;
+  x.inv = 1.f / (float)((H / 2) * (W / 2));
+  x.act = ACT_SILU;
+  std::vector<Ref> outs(blocks.size() + 1);
+  outs[0] = x;
   for (size_t i = 0; i < blocks.size(); ++i) {
     const Block& b = blocks[i];
-    Act y;
     if (mbconv(pm, bb + "_blocks." + std::to_string(i) + ".", b.stage, b.k, b.stride, b.cin,
-               b.cout, b.expand, x, &y)) return 1;
-    x = y;
-    if (nf < 3 && (int)i == taps[nf]) feats[nf++] = x;
+               b.cout, b.expand, &outs[i], &outs[i + 1])) return 1;
   }
-  JH_REQUIRE(nf == 3, "feature taps");
+  Ref feats[3];
+  for (int f = 0; f < 3; ++f) {
+    JH_REQUIRE(taps[f] >= 0 && taps[f] < (int)blocks.size(), "feature taps");
+    feats[f] = outs[taps[f] + 1];
+  }
 
   // BiFPN cells (model.py:301-353, 446-504).  Every tensor inside the pyramid is
   // kept as "raw conv output + statistics"; the fused node kernel normalises on load.
@@ -402,8 +431,7 @@ int EffTrackPlan::build(const ParamMap& pm, const std::string& pre, int size, in
     p3 = p3_out; p4 = p4_out; p5 = p5_out; p6 = p6_out; p7 = p7_out;
   }
 
-  // head: softplus-normalised 3-way fusion + first_conv as one fused node, its
-  // InstanceNorm materialised for deconv1 (model.py:119-127)
+  // head: softplus-normalised 3-way fusion + first_conv as one fused node (model.py:119-127)
   const float* wc = nullptr;
   if (get(pm, pre + "weights_cat", 3, &wc)) return 1;
   float w[3], sum = 0.f;
@@ -413,10 +441,10 @@ int EffTrackPlan::build(const ParamMap& pm, const std::string& pre, int size, in
   const int hmodes[3] = {FUSE_SAME, FUSE_UP2, FUSE_UP4};
   Ref mid;
   if (node(pm, pre + "first_conv.", 3, hin, hmodes, w, ACT_NONE, p3.a, ss.head, &mid)) return 1;
-  add_norm(mid.a, (size_t)mid.st, ACT_NONE, nullptr, nullptr, mid.a.p, -1);
+  // first_conv's InstanceNorm is applied by deconv1 while it stages its operand
   if (new_act(N, 1, mid.a.H * 2, mid.a.W * 2, J, &heat)) return 1;
   if (add_conv(pm, deconv2d_k4s2p1_desc(ss.head, J), pre + "deconv1.weight", "", true, mid.a, heat,
-               nullptr, false, nullptr)) return 1;
+               nullptr, false, nullptr, mid.st, mid.inv, ACT_NONE)) return 1;
   return finish();
 }
 
