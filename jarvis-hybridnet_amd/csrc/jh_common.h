@@ -184,6 +184,8 @@ __device__ __forceinline__ BlockId xcd_block() {
 
 struct NodeArgs;
 int launch_bifpn_node(const NodeArgs& a, hipStream_t s);
+int launch_deconv_c1(const Act& x, const double* stats, float inv_cnt, int in_act, const float* w,
+                     const Act& y, hipStream_t s);
 
 // ---------------------------------------------------------------- layout moves
 // NCHW/NCDHW fp32 -> channel-last padded (pad channels zeroed) and back.

@@ -443,6 +443,24 @@ int EffTrackPlan::build(const ParamMap& pm, const std::string& pre, int size, in
   if (node(pm, pre + "first_conv.", 3, hin, hmodes, w, ACT_NONE, p3.a, ss.head, &mid)) return 1;
   // first_conv's InstanceNorm is applied by deconv1 while it stages its operand
   if (new_act(N, 1, mid.a.H * 2, mid.a.W * 2, J, &heat)) return 1;
+  if (J == 1) {
+    // one output channel: vector-ALU kernel instead of a 16-wide MFMA column block
+    const float* wh = nullptr;
+    if (get(pm, pre + "deconv1.weight", (size_t)ss.head * 16, &wh)) return 1;
+    std::vector<float> wt((size_t)16 * mid.a.Cp, 0.f);
+    for (int c = 0; c < ss.head; ++c)
+      for (int t = 0; t < 16; ++t) wt[(size_t)t * mid.a.Cp + c] = wh[(size_t)c * 16 + t];
+    float* wd = nullptr;
+    if (upload(wt, &wd)) return 1;
+    const Act m = mid.a, h = heat;
+    const long mst = mid.st;
+    const float minv = mid.inv;
+    push("deconv_k4s2T_c1", 2.0 * N * h.pixels() * ss.head * 4,
+         4.0 * N * (m.pixels() * ss.head + (double)h.pixels() * h.Cp), [this, m, h, mst, minv, wd](hipStream_t s) {
+      return launch_deconv_c1(m, mst >= 0 ? sc((size_t)mst) : nullptr, minv, ACT_NONE, wd, h, s);
+    });
+    return finish();
+  }
   if (add_conv(pm, deconv2d_k4s2p1_desc(ss.head, J), pre + "deconv1.weight", "", true, mid.a, heat,
                nullptr, false, nullptr, mid.st, mid.inv, ACT_NONE)) return 1;
   return finish();
