@@ -200,8 +200,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   const int nb16_total = a.cout_p16 >> 4;
   // per-lane weight base; column blocks past the end are clamped (their results are
   // never stored), so the main loop has no conditional loads
-  const float2* __restrict__ wlane =
-      reinterpret_cast<const float2*>(a.w + (size_t)ph * a.phase_stride) + lane;
+  // (uniform base + 32-bit lane offset: the loads take the SGPR-base addressing form and
+  // their addresses are scalar arithmetic)
+  const float2* __restrict__ wbase = reinterpret_cast<const float2*>(a.w + (size_t)ph * a.phase_stride);
+  const unsigned ulane = lane;
   int boff[NR];
 #pragma unroll
   for (int nr = 0; nr < NR; ++nr) boff[nr] = min(nb0 + nr, nb16_total - 1) * 64;
@@ -245,36 +247,53 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     }
     __syncthreads();
 
-    // ---- taps: all KC8 8-channel steps of a tap are unrolled; the weights of the
-    // next tap are fetched (L2) while the current tap's MFMAs issue
-    int koff[KC8];
+    // Two forms of the tap loop.  PIPE (kernels with enough matrix work per tap): explicit
+    // one-tap-ahead operand prefetch with a prescribed issue order.  Otherwise (1x1 convs,
+    // narrow layers) the plain loop, which the compiler schedules better on its own.
+    constexpr bool PIPE = (G::NT > 1) && (MR * NR * KC8 >= 12);
+    if constexpr (PIPE) {
+      // ---- taps: all KC8 8-channel steps of a tap are unrolled.  BOTH operands of tap t+1
+      // (A rows from LDS, B columns from L2) are requested while the MFMAs of tap t issue,
+      // spread evenly between them by the sched_group_barrier sequence below; left alone
+      // the compiler sinks the weight loads to ~10 MFMAs before their use.
+      int koff[KC8];
 #pragma unroll
-    for (int k8 = 0; k8 < KC8; ++k8)
-      koff[k8] = min((c0 >> 3) + k8, nkc8_total - 1) * nb16_total * 64;
-    float2 bn[KC8][NR];
+      for (int k8 = 0; k8 < KC8; ++k8)
+        koff[k8] = min((c0 >> 3) + k8, nkc8_total - 1) * nb16_total * 64;
+      float2 bn[KC8][NR], an[KC8][MR];
 #pragma unroll
-    for (int k8 = 0; k8 < KC8; ++k8)
+      for (int k8 = 0; k8 < KC8; ++k8) {
 #pragma unroll
-      for (int nr = 0; nr < NR; ++nr) bn[k8][nr] = wlane[koff[k8] + boff[nr]];
-    int tap = 0;
-    for (int dz = 0; dz < G::KD; ++dz)
-      for (int dy = 0; dy < G::KH; ++dy) {
+        for (int nr = 0; nr < NR; ++nr) bn[k8][nr] = (wbase + koff[k8] + boff[nr])[ulane];
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) an[k8][mr] = lds2[abase[mr] + k8 * 4];
+      }
+      for (int row = 0; row < G::KD * G::KH; ++row) {
+        const int dz = row / G::KH, dy = row % G::KH;
         const int row_off = (dz * G::PY + dy) * G::PX * S2;
+        const int nrow = min(row + 1, G::KD * G::KH - 1);
+        const int next_row_off = ((nrow / G::KH) * G::PY + nrow % G::KH) * G::PX * S2;
 #pragma unroll
-        for (int dx = 0; dx < G::KW; ++dx, ++tap) {
+        for (int dx = 0; dx < G::KW; ++dx) {
+          const int tap = row * G::KW + dx;
           float2 bc[KC8][NR], ac[KC8][MR];
 #pragma unroll
-          for (int k8 = 0; k8 < KC8; ++k8)
+          for (int k8 = 0; k8 < KC8; ++k8) {
 #pragma unroll
-            for (int mr = 0; mr < MR; ++mr) ac[k8][mr] = lds2[abase[mr] + row_off + dx * S2 + k8 * 4];
-          const float2* wn = wlane + (size_t)min(tap + 1, G::NT - 1) * tap_stride;
+            for (int mr = 0; mr < MR; ++mr) ac[k8][mr] = an[k8][mr];
 #pragma unroll
-          for (int k8 = 0; k8 < KC8; ++k8)
+            for (int nr = 0; nr < NR; ++nr) bc[k8][nr] = bn[k8][nr];
+          }
+          // operands of the next tap (the last tap re-requests itself: results unused)
+          const float2* wn = wbase + (size_t)min(tap + 1, G::NT - 1) * tap_stride;
+          const int noff = (dx + 1 < G::KW) ? row_off + (dx + 1) * S2 : next_row_off;
 #pragma unroll
-            for (int nr = 0; nr < NR; ++nr) {
-              bc[k8][nr] = bn[k8][nr];
-              bn[k8][nr] = wn[koff[k8] + boff[nr]];
-            }
+          for (int k8 = 0; k8 < KC8; ++k8) {
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) bn[k8][nr] = (wn + koff[k8] + boff[nr])[ulane];
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr) an[k8][mr] = lds2[abase[mr] + noff + k8 * 4];
+          }
 #pragma unroll
           for (int k8 = 0; k8 < KC8; ++k8) {
 #pragma unroll
@@ -288,8 +307,74 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
               for (int nr = 0; nr < NR; ++nr)
                 acc[mr][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[k8][mr].y, bc[k8][nr].y, acc[mr][nr], 0, 0, 0);
           }
+          // issue order of this tap: its loads (which feed the NEXT tap) spread evenly
+          // between its MFMAs, weights first
+          {
+            constexpr int MPK = MR * NR * 2, LPK = NR + MR, EACH = MPK / LPK, REM = MPK - EACH * LPK;
+#pragma unroll
+            for (int k8 = 0; k8 < KC8; ++k8) {
+#pragma unroll
+              for (int j = 0; j < NR; ++j) {
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // VMEM read
+                __builtin_amdgcn_sched_group_barrier(0x008, EACH, 0);   // MFMA
+              }
+#pragma unroll
+              for (int j = 0; j < MR; ++j) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS read
+                __builtin_amdgcn_sched_group_barrier(0x008, EACH, 0);
+              }
+              if (REM > 0) __builtin_amdgcn_sched_group_barrier(0x008, REM, 0);
+            }
+          }
         }
       }
+    } else {
+      // ---- taps: all KC8 8-channel steps of a tap are unrolled; the weights of the
+      // next tap are fetched (L2) while the current tap's MFMAs issue
+      int koff[KC8];
+#pragma unroll
+      for (int k8 = 0; k8 < KC8; ++k8)
+        koff[k8] = min((c0 >> 3) + k8, nkc8_total - 1) * nb16_total * 64;
+      float2 bn[KC8][NR];
+#pragma unroll
+      for (int k8 = 0; k8 < KC8; ++k8)
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) bn[k8][nr] = (wbase + ulane)[koff[k8] + boff[nr]];
+      int tap = 0;
+      for (int dz = 0; dz < G::KD; ++dz)
+        for (int dy = 0; dy < G::KH; ++dy) {
+          const int row_off = (dz * G::PY + dy) * G::PX * S2;
+#pragma unroll
+          for (int dx = 0; dx < G::KW; ++dx, ++tap) {
+            float2 bc[KC8][NR], ac[KC8][MR];
+#pragma unroll
+            for (int k8 = 0; k8 < KC8; ++k8)
+#pragma unroll
+              for (int mr = 0; mr < MR; ++mr) ac[k8][mr] = lds2[abase[mr] + row_off + dx * S2 + k8 * 4];
+            const float2* wn = (wbase + ulane) + (size_t)min(tap + 1, G::NT - 1) * tap_stride;
+#pragma unroll
+            for (int k8 = 0; k8 < KC8; ++k8)
+#pragma unroll
+              for (int nr = 0; nr < NR; ++nr) {
+                bc[k8][nr] = bn[k8][nr];
+                bn[k8][nr] = wn[koff[k8] + boff[nr]];
+              }
+#pragma unroll
+            for (int k8 = 0; k8 < KC8; ++k8) {
+#pragma unroll
+              for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr)
+                  acc[mr][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[k8][mr].x, bc[k8][nr].x, acc[mr][nr], 0, 0, 0);
+#pragma unroll
+              for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr)
+                  acc[mr][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[k8][mr].y, bc[k8][nr].y, acc[mr][nr], 0, 0, 0);
+            }
+          }
+        }
+    }
   }
 
   // ---- epilogue: bias, store, InstanceNorm statistics
