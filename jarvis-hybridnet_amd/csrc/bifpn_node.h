@@ -17,6 +17,7 @@ struct NodeArgs {
   float* y;                // raw output [N][H][W][cout_p]
   double* stats;           // [N][cout_p][2]
   int N, H, W, Cp, cout_p, cout_p16, cf;
+  int blds = 0;            // pointwise weights staged in LDS behind the operand tile
   int alias = 0;           // operand tile written over the halo tile (single channel chunk)
   int abl = 0;             // ablation bits for timing experiments (0 in production)   // cf = channels per halo chunk (multiple of 4)
 };

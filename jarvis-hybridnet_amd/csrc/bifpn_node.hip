@@ -60,7 +60,7 @@ __device__ __forceinline__ float node_act(float v, int act) {
 // halo loads of several items can be issued back to back (no data-dependent branches),
 // which is what hides the HBM latency of this otherwise latency-bound prologue.
 template <int NIN, int M0, int M1, int M2>
-__global__ __launch_bounds__(512) void bifpn_node_kernel(const NodeArgs a) {
+__global__ __launch_bounds__(512, 6) void bifpn_node_kernel(const NodeArgs a) {
   constexpr int kModes[3] = {M0, M1, M2};
   // items in flight per thread: 512 x 5 covers a whole 56-channel halo tile in one round
   // trip; with three inputs that costs > 80 VGPRs, i.e. the third workgroup per CU, which
@@ -78,7 +78,11 @@ __global__ __launch_bounds__(512) void bifpn_node_kernel(const NodeArgs a) {
   // With a single channel chunk the operand tile is built in registers and then written
   // OVER the halo tile (a.alias): 44 KB instead of 77 KB of LDS, 3 workgroups per CU.
   float* At = a.alias ? Ft : Ft + kNodePY * kNodePX * SF;      // [128][SA]
-  float* red = a.alias ? At + 128 * SA : Ft;     // epilogue reduction scratch
+  // a.blds: the packed pointwise weights (<= 16 KB) sit behind the operand tile in LDS, so
+  // the MFMA loop has no L2 round trips (it was L2-latency-bound: 8 MFMAs per iteration
+  // cannot cover a weight fetch).  The epilogue scratch then reuses the dead operand tile.
+  float* Bl = At + 128 * SA;                     // [Cp/8][cout_p16/16][64][2]
+  float* red = a.alias ? (a.blds ? At : At + 128 * SA) : Ft;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6, mrow = lane & 15, kq = lane >> 4;
   const int tiles_x = (a.W + kNodeTX - 1) / kNodeTX;
@@ -167,6 +171,7 @@ __global__ __launch_bounds__(512) void bifpn_node_kernel(const NodeArgs a) {
     // <= 2r+1, which no later round reads; the barrier orders this round's reads
     // before its writes.
     const int ditems = (a.abl & 2) ? 0 : 32 * q;
+    const bool bact = a.blds && tid * 8 < nk8 * nb * 128;
 #pragma unroll 1
     for (int r = 0; r < kNodeTY / 2; ++r) {
       float4 dacc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -185,6 +190,12 @@ __global__ __launch_bounds__(512) void bifpn_node_kernel(const NodeArgs a) {
       }
       if (a.alias) __syncthreads();
       if (tid < ditems) *reinterpret_cast<float4*>(At + p * SA + cf0 + c4 * 4) = dacc;
+    }
+    if (bact) {                                  // (the last round's barrier has passed: the
+      const float4 b0 = *reinterpret_cast<const float4*>(a.pw + tid * 8);     // halo tile is dead)
+      const float4 b1 = *reinterpret_cast<const float4*>(a.pw + tid * 8 + 4);
+      *reinterpret_cast<float4*>(Bl + tid * 8) = b0;
+      *reinterpret_cast<float4*>(Bl + tid * 8 + 4) = b1;
     }
     __syncthreads();
   }
@@ -207,24 +218,41 @@ __global__ __launch_bounds__(512) void bifpn_node_kernel(const NodeArgs a) {
     int boff[kNodeNRG];
 #pragma unroll
     for (int nr = 0; nr < kNodeNRG; ++nr) boff[nr] = min(nb0 + nr, nb - 1) * 64;
-    float2 bn[kNodeNRG], bnn[kNodeNRG];
+    if (a.blds) {
+      const float2* B2 = reinterpret_cast<const float2*>(Bl) + lane;
+#pragma unroll 1
+      for (int k8 = 0; k8 < nk8; ++k8) {
+        const float2 ac = A2[abase + k8 * 4];
+        float2 bc[kNodeNRG];
 #pragma unroll
-    for (int nr = 0; nr < kNodeNRG; ++nr) {
-      bn[nr] = wl[boff[nr]];
-      bnn[nr] = wl[(size_t)min(1, nk8 - 1) * nb * 64 + boff[nr]];
-    }
-    for (int k8 = 0; k8 < nk8; ++k8) {
-      float2 bc[kNodeNRG];
-      const float2 ac = A2[abase + k8 * 4];
-      const float2* wn = wl + (size_t)min(k8 + 2, nk8 - 1) * nb * 64;
+        for (int nr = 0; nr < kNodeNRG; ++nr) bc[nr] = B2[k8 * nb * 64 + boff[nr]];
 #pragma unroll
-      for (int nr = 0; nr < kNodeNRG; ++nr) { bc[nr] = bn[nr]; bn[nr] = bnn[nr]; bnn[nr] = wn[boff[nr]]; }
+        for (int nr = 0; nr < kNodeNRG; ++nr)
+          acc[0][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac.x, bc[nr].x, acc[0][nr], 0, 0, 0);
 #pragma unroll
-      for (int nr = 0; nr < kNodeNRG; ++nr)
-        acc[0][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac.x, bc[nr].x, acc[0][nr], 0, 0, 0);
+        for (int nr = 0; nr < kNodeNRG; ++nr)
+          acc[0][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac.y, bc[nr].y, acc[0][nr], 0, 0, 0);
+      }
+    } else {
+      float2 bn[kNodeNRG], bnn[kNodeNRG];
 #pragma unroll
-      for (int nr = 0; nr < kNodeNRG; ++nr)
-        acc[0][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac.y, bc[nr].y, acc[0][nr], 0, 0, 0);
+      for (int nr = 0; nr < kNodeNRG; ++nr) {
+        bn[nr] = wl[boff[nr]];
+        bnn[nr] = wl[(size_t)min(1, nk8 - 1) * nb * 64 + boff[nr]];
+      }
+      for (int k8 = 0; k8 < nk8; ++k8) {
+        float2 bc[kNodeNRG];
+        const float2 ac = A2[abase + k8 * 4];
+        const float2* wn = wl + (size_t)min(k8 + 2, nk8 - 1) * nb * 64;
+#pragma unroll
+        for (int nr = 0; nr < kNodeNRG; ++nr) { bc[nr] = bn[nr]; bn[nr] = bnn[nr]; bnn[nr] = wn[boff[nr]]; }
+#pragma unroll
+        for (int nr = 0; nr < kNodeNRG; ++nr)
+          acc[0][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac.x, bc[nr].x, acc[0][nr], 0, 0, 0);
+#pragma unroll
+        for (int nr = 0; nr < kNodeNRG; ++nr)
+          acc[0][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac.y, bc[nr].y, acc[0][nr], 0, 0, 0);
+      }
     }
     __syncthreads();          // the scratch may be the (dead) halo tile
     if (!(a.abl & 8)) conv_epilogue<1, kNodeNRG, kNodeTY, kNodeTX, 8>(acc, e, red, nb0, 0, oy0, ox0, tid);
@@ -256,13 +284,17 @@ int launch_bifpn_node(const NodeArgs& args, hipStream_t s) {
   const size_t halo_px = (size_t)kNodePY * kNodePX * sizeof(float);
   // preferred: the whole channel range in one halo chunk, operand tile aliased onto it
   // (3 workgroups per CU for the 56-channel pyramid of the small model)
-  size_t lds = head + std::max(halo_px * a.Cp, at_bytes + red);
+  const size_t b_bytes = (size_t)(a.Cp / 8) * (a.cout_p16 / 16) * 128 * sizeof(float);
+  a.blds = (b_bytes <= 16 * 1024) ? 1 : 0;        // 512 threads x 32 bytes
+  if (const char* e = getenv("JH_NODE_NOBLDS")) { if (atoi(e)) a.blds = 0; }
+  size_t lds = head + std::max(halo_px * a.Cp, at_bytes + (a.blds ? b_bytes : red));
   a.cf = a.Cp;
   a.alias = 1;
   const char* na = getenv("JH_NODE_NOALIAS");
   if (a.Cp > 64 || a.Cp < 32 || lds > 54 * 1024 || (na && atoi(na))) {
     // fallback: separate operand tile, halo chunked to the LDS budget
     a.alias = 0;
+    a.blds = 0;
     size_t budget = 78 * 1024;
     if (const char* e = getenv("JH_NODE_LDS_KB")) budget = (size_t)atoi(e) * 1024;
     const size_t fixed = head + at_bytes;
