@@ -48,6 +48,31 @@ __device__ __forceinline__ float4 node_fetch(const float* in, int mode, int n, i
                      fmaxf(fmaxf(a0.z, a1.z), fmaxf(a2.z, a3.z)), fmaxf(fmaxf(a0.w, a1.w), fmaxf(a2.w, a3.w)));
 }
 
+// Same, for the single-chunk kernel: `b` is the (uniform) base of image n of the input at
+// ITS resolution, offsets are 32-bit.
+__device__ __forceinline__ float4 node_fetch_n(const float* b, int mode, int oy, int ox, int H, int W,
+                                               int Cp, int c) {
+  if (mode == FUSE_SAME) return *reinterpret_cast<const float4*>(b + ((oy * W + ox) * Cp + c));
+  if (mode == FUSE_UP2)
+    return *reinterpret_cast<const float4*>(b + (((oy >> 1) * (W >> 1) + (ox >> 1)) * Cp + c));
+  if (mode == FUSE_UP4)
+    return *reinterpret_cast<const float4*>(b + (((oy >> 2) * (W >> 2) + (ox >> 2)) * Cp + c));
+  const int w = W * 2;                // FUSE_POOL2 (max commutes with the monotone IN map)
+  const float* s = b + ((oy * 2 * w + ox * 2) * Cp + c);
+  const float4 a0 = *reinterpret_cast<const float4*>(s);
+  const float4 a1 = *reinterpret_cast<const float4*>(s + Cp);
+  const float4 a2 = *reinterpret_cast<const float4*>(s + w * Cp);
+  const float4 a3 = *reinterpret_cast<const float4*>(s + w * Cp + Cp);
+  return make_float4(fmaxf(fmaxf(a0.x, a1.x), fmaxf(a2.x, a3.x)), fmaxf(fmaxf(a0.y, a1.y), fmaxf(a2.y, a3.y)),
+                     fmaxf(fmaxf(a0.z, a1.z), fmaxf(a2.z, a3.z)), fmaxf(fmaxf(a0.w, a1.w), fmaxf(a2.w, a3.w)));
+}
+__device__ __forceinline__ size_t node_plane(int mode, int H, int W) {
+  if (mode == FUSE_SAME) return (size_t)H * W;
+  if (mode == FUSE_UP2) return (size_t)(H >> 1) * (W >> 1);
+  if (mode == FUSE_UP4) return (size_t)(H >> 2) * (W >> 2);
+  return (size_t)H * W * 4;
+}
+
 __device__ __forceinline__ float node_act(float v, int act) {
   // SiLU with the hardware exp2 / reciprocal (about 1e-7 relative error; the prologue is
   // instruction-bound on the IEEE expf + division otherwise)
@@ -59,13 +84,13 @@ __device__ __forceinline__ float node_act(float v, int act) {
 // The resampling modes are template parameters: with them known at compile time the
 // halo loads of several items can be issued back to back (no data-dependent branches),
 // which is what hides the HBM latency of this otherwise latency-bound prologue.
-template <int NIN, int M0, int M1, int M2>
+template <int NIN, int M0, int M1, int M2, bool ONE>
 __global__ __launch_bounds__(512, 6) void bifpn_node_kernel(const NodeArgs a) {
   constexpr int kModes[3] = {M0, M1, M2};
   // items in flight per thread: 512 x 5 covers a whole 56-channel halo tile in one round
   // trip; with three inputs that costs > 80 VGPRs, i.e. the third workgroup per CU, which
   // is worth more than the single round trip
-  constexpr int U = NIN == 3 ? 3 : 5;
+  constexpr int U = ONE ? (NIN == 3 ? 2 : 4) : (NIN == 3 ? 3 : 5);
   constexpr int NT = 512;                        // threads (8 waves: latency-bound prologue)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int Cp = a.Cp;
@@ -112,92 +137,202 @@ __global__ __launch_bounds__(512, 6) void bifpn_node_kernel(const NodeArgs a) {
   }
   __syncthreads();
 
-  // 2. fused halo tile -> depthwise -> operand tile, one channel chunk at a time
-  for (int cf0 = 0; cf0 < Cp; cf0 += a.cf) {
-    const int cw = min(a.cf, Cp - cf0);          // multiple of 4
-    const int q = cw >> 2;
-    const int total = kNodePY * kNodePX * q;
-    for (int b0 = 0; b0 < total; b0 += NT * U) {
-      const int base = b0 + tid;
+  // 2. fused halo tile -> depthwise -> operand tile
+  if constexpr (ONE) {
+    // Single channel chunk (Cp <= 64, operand tile aliased onto the halo tile).  The kernel
+    // is bound by vector-ALU issue, the halo phase by its index arithmetic, so this form has
+    // none to speak of: thread -> (channel quad c4 = tid % 16, pixel slot tid / 16), pixel
+    // coordinates advance incrementally (+32 pixels = +1 row +14 columns of the 18-wide
+    // halo tile), offsets are 32-bit relative to a uniform per-image base.  16 - q of every
+    // 16 lanes idle (q = 14 for the 56-channel pyramid).
+    const int q = Cp >> 2;
+    const int c4 = tid & 15, slot = tid >> 4;
+    const bool cact = c4 < q;
+    const int c = c4 * 4;
+    constexpr int NPX = kNodePY * kNodePX;
+    const float* inb[NIN];
+#pragma unroll
+    for (int k = 0; k < NIN; ++k) inb[k] = a.in[k] + (size_t)n * node_plane(kModes[k], a.H, a.W) * Cp;
+    int py = slot >= kNodePX ? 1 : 0;
+    int px = slot - py * kNodePX;
+    int pix = slot;
+    for (int p0 = 0; p0 < NPX; p0 += 32 * U) {
       float4 v[U][NIN];
       bool ok[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int idx = base + u * NT;
-        const int c4 = idx % q, pix = idx / q;
-        const int px = pix % kNodePX, py = pix / kNodePX;
         const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
-        ok[u] = idx < total && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        ok[u] = cact && pix + u * 32 < NPX && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
 #pragma unroll
         for (int k = 0; k < NIN; ++k)
-          v[u][k] = ok[u] ? node_fetch(a.in[k], kModes[k], n, iy, ix, a.H, a.W, Cp, cf0 + c4 * 4)
+          v[u][k] = ok[u] ? node_fetch_n(inb[k], kModes[k], iy, ix, a.H, a.W, Cp, c)
                           : make_float4(0.f, 0.f, 0.f, 0.f);
+        px += 32 - kNodePX; py += 1;
+        if (px >= kNodePX) { px -= kNodePX; py += 1; }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int idx = base + u * NT;
-        if (idx >= total) break;
-        const int c4 = idx % q, pix = idx / q;
-        const int c = cf0 + c4 * 4;
-        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok[u]) {
+        const int pu = pix + u * 32;
+        if (pu < NPX && cact) {
+          float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (ok[u]) {
 #pragma unroll
-          for (int k = 0; k < NIN; ++k) {
-            float4 x = v[u][k];
-            const float4 mu = *reinterpret_cast<const float4*>(mr_ + k * Cp + c);
-            const float4 rs = *reinterpret_cast<const float4*>(mr_ + 3 * Cp + k * Cp + c);
-            x.x = (x.x - mu.x) * rs.x; x.y = (x.y - mu.y) * rs.y;
-            x.z = (x.z - mu.z) * rs.z; x.w = (x.w - mu.w) * rs.w;
-            const float wk = a.w[k];
-            if (k == 0) {
-              r = make_float4(__fmul_rn(wk, x.x), __fmul_rn(wk, x.y), __fmul_rn(wk, x.z), __fmul_rn(wk, x.w));
-            } else {
-              r.x = __fadd_rn(r.x, __fmul_rn(wk, x.x)); r.y = __fadd_rn(r.y, __fmul_rn(wk, x.y));
-              r.z = __fadd_rn(r.z, __fmul_rn(wk, x.z)); r.w = __fadd_rn(r.w, __fmul_rn(wk, x.w));
+            for (int k = 0; k < NIN; ++k) {
+              float4 x = v[u][k];
+              const float4 mu = *reinterpret_cast<const float4*>(mr_ + k * Cp + c);
+              const float4 rs = *reinterpret_cast<const float4*>(mr_ + 3 * Cp + k * Cp + c);
+              x.x = (x.x - mu.x) * rs.x; x.y = (x.y - mu.y) * rs.y;
+              x.z = (x.z - mu.z) * rs.z; x.w = (x.w - mu.w) * rs.w;
+              const float wk = a.w[k];
+              if (k == 0) {
+                r = make_float4(__fmul_rn(wk, x.x), __fmul_rn(wk, x.y), __fmul_rn(wk, x.z), __fmul_rn(wk, x.w));
+              } else {
+                r.x = __fadd_rn(r.x, __fmul_rn(wk, x.x)); r.y = __fadd_rn(r.y, __fmul_rn(wk, x.y));
+                r.z = __fadd_rn(r.z, __fmul_rn(wk, x.z)); r.w = __fadd_rn(r.w, __fmul_rn(wk, x.w));
+              }
+            }
+            if (!(a.abl & 1)) {
+              r.x = node_act(r.x, a.act); r.y = node_act(r.y, a.act);
+              r.z = node_act(r.z, a.act); r.w = node_act(r.w, a.act);
             }
           }
-          if (!(a.abl & 1)) {
-            r.x = node_act(r.x, a.act); r.y = node_act(r.y, a.act);
-            r.z = node_act(r.z, a.act); r.w = node_act(r.w, a.act);
-          }
+          *reinterpret_cast<float4*>(Ft + pu * SF + c) = r;
         }
-        *reinterpret_cast<float4*>(Ft + pix * SF + c4 * 4) = r;
+      }
+      pix += 32 * U;
+    }
+    __syncthreads();
+    // depthwise 3x3: the kernel's on-chip floor is LDS bandwidth, and the depthwise reads were
+    // two thirds of it (9 data + 9 weight quads per output quad).  Each thread therefore owns
+    // a 1 x 4 strip of outputs of its channel quad (32 strips x 16 lanes = the whole tile in
+    // one round) and walks it tap row by tap row: 3 weight + 6 data quads per row feed 12
+    // FMAs x 4 channels, i.e. 6.75 instead of 18 LDS quads per output quad.  All reads of the
+    // halo tile precede the barrier, all writes of the aliased operand tile follow it.
+    const bool dact = cact && !(a.abl & 2);
+    const bool bact = a.blds && tid * 8 < nk8 * nb * 128;
+    const int sty = slot >> 2, stx = (slot & 3) * 4;
+    float4 dacc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dacc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (dact) {
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        float4 wv[3], xv[6];
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) wv[dx] = *reinterpret_cast<const float4*>(dwl + (dy * 3 + dx) * Cp + c);
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+          xv[j] = *reinterpret_cast<const float4*>(Ft + ((sty + dy) * kNodePX + stx + j) * SF + c);
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            dacc[i].x = fmaf(xv[i + dx].x, wv[dx].x, dacc[i].x); dacc[i].y = fmaf(xv[i + dx].y, wv[dx].y, dacc[i].y);
+            dacc[i].z = fmaf(xv[i + dx].z, wv[dx].z, dacc[i].z); dacc[i].w = fmaf(xv[i + dx].w, wv[dx].w, dacc[i].w);
+          }
       }
     }
     __syncthreads();
-    // depthwise 3x3, two output rows (32 pixels x q channel quads <= 512 items) per round.
-    // When the operand tile aliases the halo tile the rounds are what makes that legal:
-    // operand rows <= 2r+1 (stride SA <= 18 * SF / 16 floats) only overwrite halo rows
-    // <= 2r+1, which no later round reads; the barrier orders this round's reads
-    // before its writes.
-    const int ditems = (a.abl & 2) ? 0 : 32 * q;
-    const bool bact = a.blds && tid * 8 < nk8 * nb * 128;
-#pragma unroll 1
-    for (int r = 0; r < kNodeTY / 2; ++r) {
-      float4 dacc = make_float4(0.f, 0.f, 0.f, 0.f);
-      const int c4 = tid % q, p = r * 32 + tid / q;
-      const int tx = p % kNodeTX, ty = p / kNodeTX;
-      if (tid < ditems) {
+    if (dact) {
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-          for (int dx = 0; dx < 3; ++dx) {
-            const float4 v = *reinterpret_cast<const float4*>(Ft + ((ty + dy) * kNodePX + tx + dx) * SF + c4 * 4);
-            const float4 k = *reinterpret_cast<const float4*>(dwl + (dy * 3 + dx) * Cp + cf0 + c4 * 4);
-            dacc.x = fmaf(v.x, k.x, dacc.x); dacc.y = fmaf(v.y, k.y, dacc.y);
-            dacc.z = fmaf(v.z, k.z, dacc.z); dacc.w = fmaf(v.w, k.w, dacc.w);
-          }
-      }
-      if (a.alias) __syncthreads();
-      if (tid < ditems) *reinterpret_cast<float4*>(At + p * SA + cf0 + c4 * 4) = dacc;
+      for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<float4*>(At + (sty * kNodeTX + stx + i) * SA + c) = dacc[i];
     }
-    if (bact) {                                  // (the last round's barrier has passed: the
-      const float4 b0 = *reinterpret_cast<const float4*>(a.pw + tid * 8);     // halo tile is dead)
+    if (bact) {                                  // (the barrier has passed: the halo tile is dead)
+      const float4 b0 = *reinterpret_cast<const float4*>(a.pw + tid * 8);
       const float4 b1 = *reinterpret_cast<const float4*>(a.pw + tid * 8 + 4);
       *reinterpret_cast<float4*>(Bl + tid * 8) = b0;
       *reinterpret_cast<float4*>(Bl + tid * 8 + 4) = b1;
     }
     __syncthreads();
+  } else {
+    // general form: one channel chunk at a time (models with wider pyramids)
+    for (int cf0 = 0; cf0 < Cp; cf0 += a.cf) {
+      const int cw = min(a.cf, Cp - cf0);          // multiple of 4
+      const int q = cw >> 2;
+      const int total = kNodePY * kNodePX * q;
+      for (int b0 = 0; b0 < total; b0 += NT * U) {
+        const int base = b0 + tid;
+        float4 v[U][NIN];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int idx = base + u * NT;
+          const int c4 = idx % q, pix = idx / q;
+          const int px = pix % kNodePX, py = pix / kNodePX;
+          const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+          ok[u] = idx < total && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+#pragma unroll
+          for (int k = 0; k < NIN; ++k)
+            v[u][k] = ok[u] ? node_fetch(a.in[k], kModes[k], n, iy, ix, a.H, a.W, Cp, cf0 + c4 * 4)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int idx = base + u * NT;
+          if (idx >= total) break;
+          const int c4 = idx % q, pix = idx / q;
+          const int c = cf0 + c4 * 4;
+          float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (ok[u]) {
+#pragma unroll
+            for (int k = 0; k < NIN; ++k) {
+              float4 x = v[u][k];
+              const float4 mu = *reinterpret_cast<const float4*>(mr_ + k * Cp + c);
+              const float4 rs = *reinterpret_cast<const float4*>(mr_ + 3 * Cp + k * Cp + c);
+              x.x = (x.x - mu.x) * rs.x; x.y = (x.y - mu.y) * rs.y;
+              x.z = (x.z - mu.z) * rs.z; x.w = (x.w - mu.w) * rs.w;
+              const float wk = a.w[k];
+              if (k == 0) {
+                r = make_float4(__fmul_rn(wk, x.x), __fmul_rn(wk, x.y), __fmul_rn(wk, x.z), __fmul_rn(wk, x.w));
+              } else {
+                r.x = __fadd_rn(r.x, __fmul_rn(wk, x.x)); r.y = __fadd_rn(r.y, __fmul_rn(wk, x.y));
+                r.z = __fadd_rn(r.z, __fmul_rn(wk, x.z)); r.w = __fadd_rn(r.w, __fmul_rn(wk, x.w));
+              }
+            }
+            if (!(a.abl & 1)) {
+              r.x = node_act(r.x, a.act); r.y = node_act(r.y, a.act);
+              r.z = node_act(r.z, a.act); r.w = node_act(r.w, a.act);
+            }
+          }
+          *reinterpret_cast<float4*>(Ft + pix * SF + c4 * 4) = r;
+        }
+      }
+      __syncthreads();
+      // depthwise 3x3, two output rows (32 pixels x q channel quads <= 512 items) per round.
+      // When the operand tile aliases the halo tile the rounds are what makes that legal:
+      // operand rows <= 2r+1 (stride SA <= 18 * SF / 16 floats) only overwrite halo rows
+      // <= 2r+1, which no later round reads; the barrier orders this round's reads
+      // before its writes.
+      const int ditems = (a.abl & 2) ? 0 : 32 * q;
+      const bool bact = a.blds && tid * 8 < nk8 * nb * 128;
+#pragma unroll 1
+      for (int r = 0; r < kNodeTY / 2; ++r) {
+        float4 dacc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int c4 = tid % q, p = r * 32 + tid / q;
+        const int tx = p % kNodeTX, ty = p / kNodeTX;
+        if (tid < ditems) {
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+              const float4 v = *reinterpret_cast<const float4*>(Ft + ((ty + dy) * kNodePX + tx + dx) * SF + c4 * 4);
+              const float4 k = *reinterpret_cast<const float4*>(dwl + (dy * 3 + dx) * Cp + cf0 + c4 * 4);
+              dacc.x = fmaf(v.x, k.x, dacc.x); dacc.y = fmaf(v.y, k.y, dacc.y);
+              dacc.z = fmaf(v.z, k.z, dacc.z); dacc.w = fmaf(v.w, k.w, dacc.w);
+            }
+        }
+        if (a.alias) __syncthreads();
+        if (tid < ditems) *reinterpret_cast<float4*>(At + p * SA + cf0 + c4 * 4) = dacc;
+      }
+      if (bact) {                                  // (the last round's barrier has passed: the
+        const float4 b0 = *reinterpret_cast<const float4*>(a.pw + tid * 8);     // halo tile is dead)
+        const float4 b1 = *reinterpret_cast<const float4*>(a.pw + tid * 8 + 4);
+        *reinterpret_cast<float4*>(Bl + tid * 8) = b0;
+        *reinterpret_cast<float4*>(Bl + tid * 8 + 4) = b1;
+      }
+      __syncthreads();
+    }
   }
 
   // 3. pointwise convolution on the matrix cores: wave w owns pixels 16w .. 16w+15
@@ -260,9 +395,9 @@ __global__ __launch_bounds__(512, 6) void bifpn_node_kernel(const NodeArgs a) {
   }
 }
 
-template <int NIN, int M0, int M1, int M2>
-static int launch_node_variant(const NodeArgs& a, size_t lds, hipStream_t s) {
-  auto kern = bifpn_node_kernel<NIN, M0, M1, M2>;
+template <int NIN, int M0, int M1, int M2, bool ONE>
+static int launch_node_one(const NodeArgs& a, size_t lds, hipStream_t s) {
+  auto kern = bifpn_node_kernel<NIN, M0, M1, M2, ONE>;
   static bool big = false;
   if (lds > 64 * 1024 && !big) {
     JH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -273,6 +408,12 @@ static int launch_node_variant(const NodeArgs& a, size_t lds, hipStream_t s) {
   hipLaunchKernelGGL(kern, dim3(tiles, a.N), dim3(512), lds, s, a);
   JH_CHECK_HIP(hipGetLastError());
   return 0;
+}
+
+template <int NIN, int M0, int M1, int M2>
+static int launch_node_variant(const NodeArgs& a, size_t lds, hipStream_t s) {
+  if (a.alias) return launch_node_one<NIN, M0, M1, M2, true>(a, lds, s);
+  return launch_node_one<NIN, M0, M1, M2, false>(a, lds, s);
 }
 
 int launch_bifpn_node(const NodeArgs& args, hipStream_t s) {
