@@ -78,7 +78,8 @@ def main():
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=dev)
+        import datetime
+        dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=300))
 
     from jarvis_hybridnet_amd import _native as N
     from jarvis_hybridnet_amd import synthetic as S
@@ -304,6 +305,36 @@ def main():
             line["parity_max_abs_mm_vs_reference_fixture"] = float(
                 np.abs(res[0][0].cpu().numpy() - gold[0]).max())
 
+    if sharded and world > 1:
+        # next to the camera-sharded number, the frame-parallel upper bound --
+        # every rank runs the whole path on its own `--time-batch` frames, no data-path
+        # collective (what a throughput-only deployment would do)
+        try:
+            del sh, pred, fr
+            torch.cuda.empty_cache()
+            Tb = args.time_batch
+            rp = NativePredictor(sd_c, sd_h, **dict(common, time_batch=Tb))
+            rp.set_calibration(*[t.to(dev) for t in calib])
+            T_keep, T = T, Tb
+            rfr = device_frames(0, c["C"])
+            T = T_keep
+            rout = (torch.empty((Tb, c["J"], 3), device=dev), torch.empty((Tb, c["J"]), device=dev),
+                    torch.empty((Tb,), device=dev, dtype=torch.int32))
+            for _ in range(max(1, args.warmup)):
+                rp.forward(rfr, rout)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                rp.forward(rfr, rout)
+            barrier()
+            tt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            line["replicas_only"] = {"value": Tb * world * args.steps / tt.item(),
+                                     "unit": "multi-view frames/s",
+                                     "note": "frame-parallel upper bound: each rank runs all %d cameras "
+                                             "of its own %d frames per step, no collective" % (c["C"], Tb)}
+        except Exception as e:                      # never lose the headline number to the extra
+            line["replicas_only"] = {"error": repr(e)[:200]}
     if sharded:
         dist.destroy_process_group()
     if rank == 0:
