@@ -74,7 +74,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     sharded = world > 1 or args.force_sharded
     if sharded:
-        os.environ["NCCL_DEBUG"] = "WARN"          # keep RCCL's version banner off stdout
+        os.environ["NCCL_DEBUG"] = "WARN"          # keep RCCL's banner and warnings off stdout:
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/jh_rccl_%h_%p.log")   # the JSON line is last
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
@@ -305,7 +306,7 @@ def main():
             line["parity_max_abs_mm_vs_reference_fixture"] = float(
                 np.abs(res[0][0].cpu().numpy() - gold[0]).max())
 
-    if sharded and world > 1:
+    if sharded and (world > 1 or os.environ.get("JH_BENCH_REPLICAS")):
         # next to the camera-sharded number, the frame-parallel upper bound --
         # every rank runs the whole path on its own `--time-batch` frames, no data-path
         # collective (what a throughput-only deployment would do)
