@@ -149,6 +149,11 @@ int launch_conv(const ConvDesc& d, const ConvWeights& w, const Act& x, const Act
   const size_t budget = 72 * 1024;
   if (d.nd == 2) {
     const int small = (a.Wout <= 8) ? 1 : 0;
+    // 16 x 16 tiles for high-resolution layers with few input channels
+    int big = (a.Wout >= 64 && a.Hout >= 64 && w.cin_p <= 32 && d.ostride == 1 && d.stride == 1 &&
+               (d.k == 1 || d.k == 3)) ? 1 : 0;   // (measured: stride-2 layers do not gain)
+    if (const char* e = getenv("JH_CONV2D_BIG")) big = big && atoi(e);
+    if (big) return conv_launch_2d_big(a, d.k, d.stride, nr, budget, s);
     if (d.k == 1 && d.stride == 1) return conv_launch_2d_k1(a, nr, small, budget, s);
     if (d.k == 2 && d.stride == 1) return conv_launch_2d_k2(a, nr, small, budget, s);
     if (d.k == 3 && d.stride <= 2) return conv_launch_2d_k3(a, d.stride, nr, small, budget, s);
