@@ -45,6 +45,9 @@ HYBRID_CASES = {
                  focal=900.0, wseed=40, fseed=41),
     "cfg3": dict(C=12, J=23, roi=128, spacing=2, bbox=256, W=1280, H=1024,
                  focal=1800.0, wseed=40, fseed=42),
+    # BASELINE configs[4] geometry: 16 cameras, 30 keypoints, 96^3 grid
+    "cfg5": dict(C=16, J=30, roi=192, spacing=2, bbox=256, W=1280, H=1024,
+                 focal=1800.0, wseed=43, fseed=44),
 }
 
 PREDICTOR_CASES = {

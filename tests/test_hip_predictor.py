@@ -22,7 +22,7 @@ def make_cfg(c, center_size=256):
               HYBRIDNET=NS(NUM_CAMERAS=c["C"], ROI_CUBE_SIZE=c["roi"], GRID_SPACING=c["spacing"]))
 
 
-@pytest.mark.parametrize("tag", ["cfg2", "cfg3"])
+@pytest.mark.parametrize("tag", ["cfg2", "cfg3", "cfg5"])
 def test_hybridnet_backbone(tag, golden):
     from jarvis_hybridnet_amd.hybridnet.hybridnet import HybridNet
     c = cases.HYBRID_CASES[tag]
