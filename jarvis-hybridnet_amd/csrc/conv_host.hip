@@ -136,6 +136,7 @@ int launch_conv(const ConvDesc& d, const ConvWeights& w, const Act& x, const Act
     a.in_stats = in->stats; a.in_inv = in->inv; a.in_act = in->act;
     a.nrm_floats = 2 * x.Cp;                 // multiple of 16 floats
   }
+  if (gate) a.nrm_floats += x.Cp;            // the gate vector of the image, behind mean / rstd
   a.N = x.N; a.Din = x.D; a.Hin = x.H; a.Win = x.W; a.cin_p = x.Cp;
   a.Dy = y.D; a.Hy = y.H; a.Wy = y.W; a.cout_p = y.Cp; a.cout_p16 = w.cout_p16;
   a.ostride = d.ostride; a.nphase = d.nphase; a.phase_stride = w.phase_stride;

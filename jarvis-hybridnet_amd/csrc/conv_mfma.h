@@ -195,6 +195,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     }
   }
 
+  // the squeeze-excite gate of image n, behind mean / rstd (read while the patch is staged)
+  float* gate_l = nrm + (a.in_stats ? 2 * a.cin_p : 0);
+  if (a.gate)
+    for (int c = tid; c < a.cin_p; c += 256) gate_l[c] = a.gate[(size_t)n * a.cin_p + c];
+
   const float* __restrict__ xin = a.x + (size_t)n * a.Din * a.Hin * a.Win * a.cin_p;
   const int nkc8_total = a.cin_p >> 3;
   const int nb16_total = a.cout_p16 >> 4;
@@ -209,43 +214,94 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   for (int nr = 0; nr < NR; ++nr) boff[nr] = min(nb0 + nr, nb16_total - 1) * 64;
   const int tap_stride = nkc8_total * nb16_total * 64;     // float2 units
 
+  // Patch staging in two halves -- issue(c0): raw global loads into registers; commit(c0):
+  // InstanceNorm / activation / gate, then LDS.  Kernels with small patches (PF: 1x1 convs and
+  // the 2D layers with few loads per thread) issue the loads of the NEXT channel pass before
+  // the MFMAs of the current one: those layers run with one to three workgroups per CU and
+  // many short passes, so nothing else hides that round trip.
+  constexpr int ITER = (G::NPIX * Q4 + 255) / 256;
+  constexpr bool PF = ITER <= 8;
+  float4 pf[PF ? ITER : 1];
+  auto patch_ok = [&](int idx, int c0, const float** src) -> bool {
+    const int c4 = idx % Q4;
+    const int pix = idx / Q4;
+    const int px = pix % G::PX;
+    const int py = (pix / G::PX) % G::PY;
+    const int pz = pix / (G::PX * G::PY);
+    const int iz = iz0 + pz, iy = iy0 + py, ix = ix0 + px;
+    const int c = c0 + c4 * 4;
+    *src = xin + ((size_t)(iz * a.Hin + iy) * a.Win + ix) * a.cin_p + c;
+    return idx < G::NPIX * Q4 && c < a.cin_p && iz >= 0 && iz < a.Din && iy >= 0 && iy < a.Hin &&
+           ix >= 0 && ix < a.Win;
+  };
+  auto finish = [&](float4 v, int c) -> float4 {       // in-range pixels only
+    if (a.in_stats) {
+      const float4 mu = *reinterpret_cast<const float4*>(nrm + c);
+      const float4 rs = *reinterpret_cast<const float4*>(nrm + a.cin_p + c);
+      v.x = (v.x - mu.x) * rs.x; v.y = (v.y - mu.y) * rs.y;
+      v.z = (v.z - mu.z) * rs.z; v.w = (v.w - mu.w) * rs.w;
+      if (a.in_act == ACT_RELU) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      } else if (a.in_act == ACT_SILU) {
+        v.x = __fdividef(v.x, 1.f + __expf(-v.x)); v.y = __fdividef(v.y, 1.f + __expf(-v.y));
+        v.z = __fdividef(v.z, 1.f + __expf(-v.z)); v.w = __fdividef(v.w, 1.f + __expf(-v.w));
+      }
+    }
+    if (a.gate) {
+      const float4 g = *reinterpret_cast<const float4*>(gate_l + c);
+      v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w;
+    }
+    return v;
+  };
+  if constexpr (PF) {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const float* src;
+      const bool ok = patch_ok(tid + it * 256, 0, &src);
+      pf[it] = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+
   for (int c0 = 0; c0 < a.cin_p; c0 += KC) {
     __syncthreads();
     // ---- stage the halo patch: [pixel][KC] with stride S; channels past cin_p read 0
-    for (int idx = tid; idx < G::NPIX * Q4; idx += 256) {
-      const int c4 = idx % Q4;
-      const int pix = idx / Q4;
-      const int px = pix % G::PX;
-      const int py = (pix / G::PX) % G::PY;
-      const int pz = pix / (G::PX * G::PY);
-      const int iz = iz0 + pz, iy = iy0 + py, ix = ix0 + px;
-      const int c = c0 + c4 * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c < a.cin_p && iz >= 0 && iz < a.Din && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) {
-        v = *reinterpret_cast<const float4*>(
-            xin + ((size_t)(iz * a.Hin + iy) * a.Win + ix) * a.cin_p + c);
-        if (a.in_stats) {
-          const float4 mu = *reinterpret_cast<const float4*>(nrm + c);
-          const float4 rs = *reinterpret_cast<const float4*>(nrm + a.cin_p + c);
-          v.x = (v.x - mu.x) * rs.x; v.y = (v.y - mu.y) * rs.y;
-          v.z = (v.z - mu.z) * rs.z; v.w = (v.w - mu.w) * rs.w;
-          if (a.in_act == ACT_RELU) {
-            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-          } else if (a.in_act == ACT_SILU) {
-            v.x = __fdividef(v.x, 1.f + __expf(-v.x)); v.y = __fdividef(v.y, 1.f + __expf(-v.y));
-            v.z = __fdividef(v.z, 1.f + __expf(-v.z)); v.w = __fdividef(v.w, 1.f + __expf(-v.w));
-          }
-        }
-        if (a.gate) {
-          const float4 g = *reinterpret_cast<const float4*>(a.gate + (size_t)n * a.cin_p + c);
-          v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w;
+    if constexpr (PF) {
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        const int idx = tid + it * 256;
+        if (idx < G::NPIX * Q4) {
+          const float* src;
+          const bool ok = patch_ok(idx, c0, &src);
+          const int c4 = idx % Q4, pix = idx / Q4;
+          const float4 v = ok ? finish(pf[it], c0 + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+          float2* dst = lds2 + pix * S2 + c4 * 2;
+          dst[0] = make_float2(v.x, v.y);
+          dst[1] = make_float2(v.z, v.w);
         }
       }
-      float2* dst = lds2 + pix * S2 + c4 * 2;
-      dst[0] = make_float2(v.x, v.y);
-      dst[1] = make_float2(v.z, v.w);
+    } else {
+      for (int idx = tid; idx < G::NPIX * Q4; idx += 256) {
+        const float* src;
+        const bool ok = patch_ok(idx, c0, &src);
+        const int c4 = idx % Q4, pix = idx / Q4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) v = finish(*reinterpret_cast<const float4*>(src), c0 + c4 * 4);
+        float2* dst = lds2 + pix * S2 + c4 * 2;
+        dst[0] = make_float2(v.x, v.y);
+        dst[1] = make_float2(v.z, v.w);
+      }
     }
     __syncthreads();
+    if constexpr (PF) {
+      if (c0 + KC < a.cin_p) {                   // next pass's loads fly under this pass's MFMAs
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+          const float* src;
+          const bool ok = patch_ok(tid + it * 256, c0 + KC, &src);
+          pf[it] = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+    }
 
     // Two forms of the tap loop.  PIPE (kernels with enough matrix work per tap): explicit
     // one-tap-ahead operand prefetch with a prescribed issue order.  Otherwise (1x1 convs,
