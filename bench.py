@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--no-uint8", action="store_true", help="skip the uint8-ingest side measurement")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="multi-GPU: do not overlap the heatmap exchange with the next step's 2D stage")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU (camera-sharded, RCCL) code path even with one rank")
     args = ap.parse_args()
@@ -148,10 +150,16 @@ def main():
             step()
         run = g.replay
         run()
+    if sharded and not args.no_pipeline:
+        # consecutive time batches pipelined: the heatmap exchange of step i runs under the
+        # CenterDetect stage of step i+1; K submits + the final flush = exactly K whole steps
+        run = lambda: sh.submit(fr)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run()
+    if sharded and not args.no_pipeline:
+        sh.flush()
     barrier()
     dt = time.perf_counter() - t0
     if sharded:
@@ -177,7 +185,8 @@ def main():
                    "frames_per_step": T * n_groups, "valid_frames_last_step": valid,
                    "parallelism": "single GPU" if not sharded else
                    "%d group(s) x %d GPUs: camera-sharded 2D (%d cams/GPU) + RCCL %s of "
-                   "heatmaps + frame-sharded 3D" % (n_groups, gs, c["C"] // gs, args.exchange),
+                   "heatmaps%s + frame-sharded 3D" % (n_groups, gs, c["C"] // gs, args.exchange,
+                                                       "" if args.no_pipeline else " (overlapped with the next step's CenterDetect)"),
                    "launches_per_step": int(pred.launches), "hipgraph": bool(args.graph)},
     }
 

@@ -20,6 +20,9 @@ new design for the 8 x MI355X node:
   stage 3   reprojection + V2V + soft-argmax for the owned frames
   gather    (T/N, J, 4) results to every rank (tiny all-gather)
 
+submit() / flush() pipeline consecutive time batches so that the bulk exchange of one
+batch runs under the CenterDetect stage of the next; step() is submit() + flush().
+
 `stages` is any object with the four methods used below, which is what lets the
 world_size-2 gloo test on CPU drive this file with the oracle as compute.
 """
@@ -61,21 +64,49 @@ class ShardedPredictor:
         self.res_all = torch.empty((world * self.T3, self.J, 4), **f32)
         self.valid_local = torch.empty((self.T3,), device=device, dtype=torch.int32)
         self.valid_all = torch.empty((world * self.T3,), device=device, dtype=torch.int32)
+        self._pending = None                     # exchange of the time batch in flight
 
     def step(self, frames_local):
         """frames_local (T, Cloc, 3, H, W) -> points (T,J,3), conf (T,J), valid (T)."""
-        W, T3, Cl = self.world, self.T3, self.Cloc
+        self.submit(frames_local)
+        return self.flush()
+
+    # ---- pipelined form: the bulk exchange of time batch i runs under the CenterDetect
+    # stage of time batch i+1 (which touches neither the heatmap buffers nor the crop
+    # centres the 3D stage of batch i still needs).  Order of one submit():
+    #     stage_center(i+1) || exchange(i)  ->  stage_3d(i)  ->  stage_keypoints(i+1)
+    #     -> exchange(i+1) started asynchronously
+    def submit(self, frames_local):
+        """Start time batch i+1; returns the results of batch i (None on the first call)."""
+        W, Cl = self.world, self.Cloc
         self.st.stage_center(frames_local, self.det_local)
         dist.all_gather_into_tensor(self.det_gather, self.det_local, group=self.group)
         det_all = (self.det_gather.view(W, self.T, Cl, 3).permute(1, 0, 2, 3)
                    .reshape(self.T, self.C, 3).contiguous())
+        prev = self._finish()
         self.st.stage_keypoints(frames_local, det_all, self.heat_local)
         if self.exchange == "alltoall":
             # block r of the send buffer = my cameras' heatmaps of rank r's frames
-            dist.all_to_all_single(self.heat_recv, self.heat_local, group=self.group)
+            self._pending = dist.all_to_all_single(self.heat_recv, self.heat_local,
+                                                   group=self.group, async_op=True)
+        else:
+            self._pending = dist.all_gather_into_tensor(self.heat_recv, self.heat_local,
+                                                        group=self.group, async_op=True)
+        return prev
+
+    def flush(self):
+        """Results of the last submitted time batch (None if nothing is in flight)."""
+        return self._finish()
+
+    def _finish(self):
+        if self._pending is None:
+            return None
+        W, T3, Cl = self.world, self.T3, self.Cloc
+        self._pending.wait()
+        self._pending = None
+        if self.exchange == "alltoall":
             mine = self.heat_recv.view((W, T3, Cl) + self.heat_recv.shape[2:])
         else:
-            dist.all_gather_into_tensor(self.heat_recv, self.heat_local, group=self.group)
             mine = self.heat_recv.view((W, self.T, Cl) + self.heat_recv.shape[2:])[
                 :, self.t_lo:self.t_lo + T3]
         # (world, T3, Cloc, ...) -> (T3, C, ...): camera c = source_rank * Cloc + local camera
@@ -87,5 +118,5 @@ class ShardedPredictor:
         self.res_local[..., 3] = conf
         dist.all_gather_into_tensor(self.res_all, self.res_local, group=self.group)
         dist.all_gather_into_tensor(self.valid_all, self.valid_local, group=self.group)
-        res = self.res_all.reshape(self.T, self.J, 4)
-        return res[..., :3], res[..., 3], self.valid_all.reshape(self.T)
+        res = self.res_all.reshape(self.T, self.J, 4).clone()      # the buffers are reused
+        return res[..., :3], res[..., 3], self.valid_all.reshape(self.T).clone()

@@ -99,7 +99,19 @@ def _worker(rank, world, port, exchange, q):
     sh = ShardedPredictor(st, num_cameras=C, num_joints=J, time_batch=T,
                           heat_shape=(BBOX // 2, BBOX // 2, JP), rank=rank, world=world,
                           device="cpu", exchange=exchange)
-    pts, conf, valid = sh.step(frames[:, lo:lo + n].contiguous())
+    mine = frames[:, lo:lo + n].contiguous()
+    pts, conf, valid = sh.step(mine)
+    # pipelined form: batch B (frames in reverse order) is submitted while batch A is in
+    # flight; every batch must come out as the unpipelined step computes it
+    rev = mine.flip(0).contiguous()
+    assert sh.submit(mine) is None
+    a = sh.submit(rev)
+    b = sh.flush()
+    assert sh.flush() is None
+    for x, y in zip(a, (pts, conf, valid)):
+        assert torch.equal(x, y), "pipelined batch A differs from step()"
+    for x, y in zip(b, (pts.flip(0), conf.flip(0), valid.flip(0))):
+        assert torch.equal(x, y), "pipelined batch B differs from step() on the same frames"
     if rank == 0:
         q.put((pts.clone(), conf.clone(), valid.clone()))
     dist.barrier()
