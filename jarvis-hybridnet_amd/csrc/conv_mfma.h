@@ -48,6 +48,7 @@ struct EpilogueArgs {
   const float* bias;
   double* stats;         // statistics row of image n, or nullptr
   int Dout, Hout, Wout, Hy, Wy, cout_p, cout_p16, os, offz, offy, offx;
+  int osz;               // output stride along z (= os except for the (y, x)-only phases of conv3d_wino)
 };
 
 // Shared epilogue of the MFMA kernels: bias, store of the raw output, and the
@@ -103,7 +104,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[MR][NR], const Epilog
       const int c0 = (nb0 + nr) * 16 + (mrow & ~3);
       if (c0 < e.cout_p && oz < e.Dout && oy < e.Hout && ox < e.Wout)
         *reinterpret_cast<float4*>(
-            e.y + ((size_t)((oz * e.os + e.offz) * e.Hy + (oy * e.os + e.offy)) * e.Wy + (ox * e.os + e.offx)) * e.cout_p + c0) =
+            e.y + ((size_t)((oz * e.osz + e.offz) * e.Hy + (oy * e.os + e.offy)) * e.Wy + (ox * e.os + e.offx)) * e.cout_p + c0) =
             make_float4(v[0], v[1], v[2], v[3]);
     }
     if (e.stats) {
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   e.bias = a.bias;
   e.stats = a.stats ? a.stats + (size_t)n * a.cout_p * 2 : nullptr;
   e.Dout = a.Dout; e.Hout = a.Hout; e.Wout = a.Wout; e.Hy = a.Hy; e.Wy = a.Wy;
-  e.cout_p = a.cout_p; e.cout_p16 = a.cout_p16; e.os = a.ostride;
+  e.cout_p = a.cout_p; e.cout_p16 = a.cout_p16; e.os = a.ostride; e.osz = a.ostride;
   e.offz = a.phase[ph].ooff[0]; e.offy = a.phase[ph].ooff[1]; e.offx = a.phase[ph].ooff[2];
   conv_epilogue<MR, NR, TY, TX>(acc, e, lds, nb0, oz0, oy0, ox0, tid);
 }

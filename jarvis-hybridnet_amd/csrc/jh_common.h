@@ -184,6 +184,9 @@ __device__ __forceinline__ BlockId xcd_block() {
 
 struct NodeArgs;
 int launch_bifpn_node(const NodeArgs& a, hipStream_t s);
+int pack_wino_weights(int cin, int cout, const float* w, const float* b, ConvWeights* out);
+int launch_conv3d_wino(const ConvWeights& w, const Act& x, const Act& y, double* stats, hipStream_t s,
+                       const InNorm* in);
 int launch_deconv_c1(const Act& x, const double* stats, float inv_cnt, int in_act, const float* w,
                      const Act& y, hipStream_t s);
 

@@ -4,6 +4,7 @@
 // are consumed under the reference's own state-dict keys.
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include "nets.h"
 #include "bifpn_node.h"
 
@@ -101,8 +102,15 @@ int Plan::add_conv(const ParamMap& pm, const ConvDesc& d, const std::string& wke
   const float *w = nullptr, *b = nullptr;
   if (get(pm, wkey, (size_t)d.cin * d.cout * taps, &w)) return 1;
   if (!bkey.empty() && get(pm, bkey, d.cout, &b)) return 1;
+  // 3x3x3 stride-1 convs (the V2V residual blocks) run as Winograd F(2x2,3x3) x direct z
+  bool wino = d.nd == 3 && d.k == 3 && d.stride == 1 && d.ostride == 1 && !transposed && !gate;
+  if (const char* e = getenv("JH_WINO")) wino = wino && atoi(e) != 0;
   ConvWeights cw;
-  if (pack_conv_weights(d, w, b, transposed, &cw)) return 1;
+  if (wino) {
+    if (pack_wino_weights(d.cin, d.cout, w, b, &cw)) return 1;
+  } else {
+    if (pack_conv_weights(d, w, b, transposed, &cw)) return 1;
+  }
   convs_.push_back(cw);
   bytes_ += cw.phase_stride * d.nphase * sizeof(float);
   size_t off = 0;
@@ -120,9 +128,10 @@ int Plan::add_conv(const ParamMap& pm, const ConvDesc& d, const std::string& wke
   snprintf(nm, sizeof nm, "conv%dd_k%ds%d%s_%dx%d@%d", d.nd, d.ostride > 1 ? (d.nd == 2 ? 4 : 2) : d.k,
            d.ostride > 1 ? 2 : d.stride, d.ostride > 1 ? "T" : "", d.cin, d.cout, y.W);
   push(nm, flops, bytes,
-       [this, d, cw, x, y, gate, want_stats, off, in_stats_off, in_inv, in_act](hipStream_t s) {
+       [this, d, cw, x, y, gate, want_stats, off, in_stats_off, in_inv, in_act, wino](hipStream_t s) {
     InNorm in;
     if (in_stats_off >= 0) { in.stats = sc((size_t)in_stats_off); in.inv = in_inv; in.act = in_act; }
+    if (wino) return launch_conv3d_wino(cw, x, y, want_stats ? sc(off) : nullptr, s, &in);
     return launch_conv(d, cw, x, y, gate, want_stats ? sc(off) : nullptr, s, &in);
   });
   return 0;
