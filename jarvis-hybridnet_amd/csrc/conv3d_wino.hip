@@ -208,54 +208,100 @@ __global__ __launch_bounds__(256) void conv3d_wino_kernel(const WinoArgs a) {
 
   // ---- output transform.  Along x inside the wave: r0 = M0 + M1 + M2, r1 = M1 - M2 - M3.
   __syncthreads();                         // R and V are dead: the exchange buffer aliases them
-  // X[(w * 2 + j)][mr][nr][i][lane]
+  // X[(w * 2 + j)][mr][nr][lane] as float4 (the 4 tile rows a lane holds of one accumulator)
+  float4* X4 = reinterpret_cast<float4*>(X);
 #pragma unroll
   for (int mr = 0; mr < kWTZ; ++mr)
 #pragma unroll
-    for (int nr = 0; nr < NR; ++nr)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float m0 = acc[0][mr][nr][i], m1 = acc[1][mr][nr][i], m2 = acc[2][mr][nr][i],
-                    m3 = acc[3][mr][nr][i];
-        X[((((wave * 2 + 0) * kWTZ + mr) * NR + nr) * 4 + i) * 64 + lane] = m0 + m1 + m2;
-        X[((((wave * 2 + 1) * kWTZ + mr) * NR + nr) * 4 + i) * 64 + lane] = m1 - m2 - m3;
-      }
+    for (int nr = 0; nr < NR; ++nr) {
+      const f32x4 m0 = acc[0][mr][nr], m1 = acc[1][mr][nr], m2 = acc[2][mr][nr], m3 = acc[3][mr][nr];
+      X4[(((wave * 2 + 0) * kWTZ + mr) * NR + nr) * 64 + lane] =
+          make_float4(m0[0] + m1[0] + m2[0], m0[1] + m1[1] + m2[1], m0[2] + m1[2] + m2[2], m0[3] + m1[3] + m2[3]);
+      X4[(((wave * 2 + 1) * kWTZ + mr) * NR + nr) * 64 + lane] =
+          make_float4(m1[0] - m2[0] - m3[0], m1[1] - m2[1] - m3[1], m1[2] - m2[2] - m3[2], m1[3] - m2[3] - m3[3]);
+    }
   __syncthreads();
   // Along y across waves (fy = wave): out[0] = P0 + P1 + P2, out[1] = P1 - P2 - P3; wave w
-  // finishes z-slice w.
-  f32x4 o[2][2][1][NR];                    // [oy][ox][1 row block][nr]
+  // finishes z-slice w: bias, statistics, 4x4 quad transpose, 16-byte stores.  A lane holds
+  // tiles (ty = kq, tx = 0..3) of channel mrow; after the transpose, tile tx = lane & 3 of
+  // channels (mrow & ~3) .. + 3.
+  float* yb = a.y + (size_t)n * a.D * a.H * a.W * a.cout_p;
+  const int jq = lane & 3;
+  const int oz = z0 + wave;
+  float s1[NR], s2[NR];
 #pragma unroll
-  for (int ox = 0; ox < 2; ++ox)
-#pragma unroll
-    for (int nr = 0; nr < NR; ++nr)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float p[4];
-#pragma unroll
-        for (int w = 0; w < 4; ++w)
-          p[w] = X[((((w * 2 + ox) * kWTZ + wave) * NR + nr) * 4 + i) * 64 + lane];
-        o[0][ox][0][nr][i] = p[0] + p[1] + p[2];
-        o[1][ox][0][nr][i] = p[1] - p[2] - p[3];
-      }
-  __syncthreads();                         // the epilogue's scratch aliases X
-  EpilogueArgs e;
-  e.y = a.y + (size_t)n * a.D * a.H * a.W * a.cout_p;
-  e.bias = a.bias;
-  e.stats = a.stats ? a.stats + (size_t)n * a.cout_p * 2 : nullptr;
-  e.Dout = a.D; e.Hy = a.H; e.Wy = a.W;
-  e.cout_p = a.cout_p; e.cout_p16 = a.cout_p16; e.os = 2; e.osz = 1;
-  // The four (oy, ox) phases are stride-2 sub-lattices in (y, x) only; z is not strided, so
-  // the phase geometry is expressed through the y / x extents and the base pointer.
-#pragma unroll
-  for (int oy = 0; oy < 2; ++oy)
+  for (int nr = 0; nr < NR; ++nr) {
+    const int ch = (nb0 + nr) * 16 + mrow;
+    const bool ch_ok = ch < a.cout_p;
+    const float bvl = (a.bias && ch < a.cout_p16) ? a.bias[ch] : 0.f;
+    s1[nr] = 0.f; s2[nr] = 0.f;
 #pragma unroll
     for (int ox = 0; ox < 2; ++ox) {
-      e.Hout = (a.H - oy + 1) / 2;
-      e.Wout = (a.W - ox + 1) / 2;
-      e.offz = 0; e.offy = oy; e.offx = ox;
-      conv_epilogue<1, NR, 4, 4>(o[oy][ox], e, X, nb0, z0, y0 >> 1, x0 >> 1, tid);
-      __syncthreads();
+      float4 p[4];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) p[w] = X4[(((w * 2 + ox) * kWTZ + wave) * NR + nr) * 64 + lane];
+#pragma unroll
+      for (int oy = 0; oy < 2; ++oy) {
+        float v[4];
+        if (oy == 0) {
+          v[0] = p[0].x + p[1].x + p[2].x; v[1] = p[0].y + p[1].y + p[2].y;
+          v[2] = p[0].z + p[1].z + p[2].z; v[3] = p[0].w + p[1].w + p[2].w;
+        } else {
+          v[0] = p[1].x - p[2].x - p[3].x; v[1] = p[1].y - p[2].y - p[3].y;
+          v[2] = p[1].z - p[2].z - p[3].z; v[3] = p[1].w - p[2].w - p[3].w;
+        }
+        const int yy = y0 + 2 * kq + oy;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] += bvl;
+          if (ch_ok && oz < a.D && yy < a.H && x0 + 2 * r + ox < a.W) {
+            s1[nr] += v[r];
+            s2[nr] += v[r] * v[r];
+          }
+        }
+        {
+          float x, y;
+          x = (jq & 1) ? v[0] : v[1]; y = quad_xor1(x); if (jq & 1) v[0] = y; else v[1] = y;
+          x = (jq & 1) ? v[2] : v[3]; y = quad_xor1(x); if (jq & 1) v[2] = y; else v[3] = y;
+          x = (jq & 2) ? v[0] : v[2]; y = quad_xor2(x); if (jq & 2) v[0] = y; else v[2] = y;
+          x = (jq & 2) ? v[1] : v[3]; y = quad_xor2(x); if (jq & 2) v[1] = y; else v[3] = y;
+        }
+        const int xx = x0 + 2 * jq + ox;
+        const int c0 = (nb0 + nr) * 16 + (mrow & ~3);
+        if (c0 < a.cout_p && oz < a.D && yy < a.H && xx < a.W)
+          *reinterpret_cast<float4*>(yb + ((size_t)(oz * a.H + yy) * a.W + xx) * a.cout_p + c0) =
+              make_float4(v[0], v[1], v[2], v[3]);
+      }
     }
+  }
+  if (a.stats) {
+    __syncthreads();                       // the reduction scratch aliases X
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+      float t1 = s1[nr], t2 = s2[nr];
+      t1 += __shfl_xor(t1, 16); t2 += __shfl_xor(t2, 16);
+      t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);
+      if (kq == 0) {
+        X[(wave * NR * 16 + nr * 16 + mrow) * 2 + 0] = t1;
+        X[(wave * NR * 16 + nr * 16 + mrow) * 2 + 1] = t2;
+      }
+    }
+    __syncthreads();
+    if (tid < NR * 16) {
+      const int ch = nb0 * 16 + tid;
+      if (ch < a.cout_p) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          t1 += X[(w * NR * 16 + tid) * 2 + 0];
+          t2 += X[(w * NR * 16 + tid) * 2 + 1];
+        }
+        double* st = a.stats + ((size_t)n * a.cout_p + ch) * 2;
+        unsafeAtomicAdd(st + 0, (double)t1);
+        unsafeAtomicAdd(st + 1, (double)t2);
+      }
+    }
+  }
 }
 
 template <int NR>
