@@ -36,14 +36,18 @@ struct WinoArgs {
   int N, D, H, W, cin_p, cout_p, cout_p16;
 };
 
-constexpr int kWTZ = 4, kWTY = 8, kWTX = 8;                 // outputs per workgroup
-constexpr int kWPZ = kWTZ + 2, kWPY = kWTY + 2, kWPX = kWTX + 2;
-constexpr int kWNP = kWPZ * kWPY * kWPX;                    // 600 patch pixels
+constexpr int kWTY = 8, kWTX = 8;                           // (y, x) outputs per workgroup
+constexpr int kWPY = kWTY + 2, kWPX = kWTX + 2;
 constexpr int kWSV = 12;                                    // V row stride (floats): b64 reads of
                                                             // 16 tiles hit 64 distinct banks
 
-template <int NR>
-__global__ __launch_bounds__(256) void conv3d_wino_kernel(const WinoArgs a) {
+// kWTZ = z-slices per workgroup: 4 (48 accumulator tiles per wave, one workgroup per CU) or
+// 2 (24 tiles, <= 256 registers and 62 KB of LDS: two workgroups per CU, so one's patch
+// staging, input transform and epilogue run under the other's MFMAs).
+template <int NR, int kWTZ>
+__global__ __launch_bounds__(256, (kWTZ == 2 ? 2 : 1)) void conv3d_wino_kernel(const WinoArgs a) {
+  constexpr int kWPZ = kWTZ + 2;
+  constexpr int kWNP = kWPZ * kWPY * kWPX;                  // 600 / 400 patch pixels
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
   const int nrm_floats = a.in_stats ? 2 * a.cin_p : 0;
   float* nrm = lds_all;
@@ -109,6 +113,14 @@ __global__ __launch_bounds__(256) void conv3d_wino_kernel(const WinoArgs a) {
   for (int nr = 0; nr < NR; ++nr) boff[nr] = min(nb0 + nr, nb - 1) * 64 + lane;
 
   for (int c0 = 0; c0 < a.cin_p; c0 += 8) {
+    // the weights of this pass's first frequency do not depend on LDS: request them now, they
+    // land under the patch commit and the input transform
+    float2 b0v[3][NR];
+#pragma unroll
+    for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+      for (int nr = 0; nr < NR; ++nr)
+        b0v[dz][nr] = U2[(size_t)((((wave * 4) * 3 + dz) * nk8 + (c0 >> 3)) * nb) * 64 + boff[nr]];
     __syncthreads();                       // previous pass: all reads of V (and R) are done
     // 1. commit the raw patch of this pass
 #pragma unroll
@@ -188,7 +200,7 @@ __global__ __launch_bounds__(256) void conv3d_wino_kernel(const WinoArgs a) {
       for (int dz = 0; dz < 3; ++dz)
 #pragma unroll
         for (int nr = 0; nr < NR; ++nr)
-          bv[dz][nr] = U2[(size_t)(((f * 3 + dz) * nk8 + kk) * nb) * 64 + boff[nr]];
+          bv[dz][nr] = fi == 0 ? b0v[dz][nr] : U2[(size_t)(((f * 3 + dz) * nk8 + kk) * nb) * 64 + boff[nr]];
 #pragma unroll
       for (int dz = 0; dz < 3; ++dz)
 #pragma unroll
@@ -227,7 +239,11 @@ __global__ __launch_bounds__(256) void conv3d_wino_kernel(const WinoArgs a) {
   // channels (mrow & ~3) .. + 3.
   float* yb = a.y + (size_t)n * a.D * a.H * a.W * a.cout_p;
   const int jq = lane & 3;
-  const int oz = z0 + wave;
+  // kWTZ = 4: wave w finishes z-slice w (both x phases); kWTZ = 2: z-slice w & 1, x phase w >> 1
+  constexpr int OXN = (kWTZ == 4) ? 2 : 1;
+  const int mr_own = (kWTZ == 4) ? wave : (wave & 1);
+  const int ox_first = (kWTZ == 4) ? 0 : (wave >> 1);
+  const int oz = z0 + mr_own;
   float s1[NR], s2[NR];
 #pragma unroll
   for (int nr = 0; nr < NR; ++nr) {
@@ -236,10 +252,11 @@ __global__ __launch_bounds__(256) void conv3d_wino_kernel(const WinoArgs a) {
     const float bvl = (a.bias && ch < a.cout_p16) ? a.bias[ch] : 0.f;
     s1[nr] = 0.f; s2[nr] = 0.f;
 #pragma unroll
-    for (int ox = 0; ox < 2; ++ox) {
+    for (int oxi = 0; oxi < OXN; ++oxi) {
+      const int ox = ox_first + oxi;
       float4 p[4];
 #pragma unroll
-      for (int w = 0; w < 4; ++w) p[w] = X4[(((w * 2 + ox) * kWTZ + wave) * NR + nr) * 64 + lane];
+      for (int w = 0; w < 4; ++w) p[w] = X4[(((w * 2 + ox) * kWTZ + mr_own) * NR + nr) * 64 + lane];
 #pragma unroll
       for (int oy = 0; oy < 2; ++oy) {
         float v[4];
@@ -304,9 +321,9 @@ __global__ __launch_bounds__(256) void conv3d_wino_kernel(const WinoArgs a) {
   }
 }
 
-template <int NR>
+template <int NR, int TZ>
 static int launch_wino_nr(const WinoArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-  auto kern = conv3d_wino_kernel<NR>;
+  auto kern = conv3d_wino_kernel<NR, TZ>;
   static bool big = false;
   if (!big) {
     JH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -369,16 +386,22 @@ int launch_conv3d_wino(const ConvWeights& w, const Act& x, const Act& y, double*
   a.N = x.N; a.D = x.D; a.H = x.H; a.W = x.W; a.cin_p = x.Cp; a.cout_p = y.Cp; a.cout_p16 = w.cout_p16;
   const int nb = w.cout_p16 / 16;
   const int nr = (nb % 3 == 0) ? 3 : ((nb % 2 == 0) ? 2 : (nb == 1 ? 1 : 3));
-  const int blocks = ((x.D + kWTZ - 1) / kWTZ) * ((x.H + kWTY - 1) / kWTY) * ((x.W + kWTX - 1) / kWTX);
+  // measured (46->46 @ 32^3, 8 volumes): 4 z-slices 0.184 ms, 2 z-slices 0.188 ms -- the second
+  // resident workgroup does not pay for the doubled per-workgroup prologue / epilogue
+  int tz = 4;
+  if (const char* e = getenv("JH_WINO_TZ")) tz = atoi(e) == 2 ? 2 : 4;
+  const int blocks = ((x.D + tz - 1) / tz) * ((x.H + kWTY - 1) / kWTY) * ((x.W + kWTX - 1) / kWTX);
   dim3 grid(blocks, (nb + nr - 1) / nr, x.N);
-  const size_t xbytes = (size_t)4 * 2 * kWTZ * nr * 4 * 64 * sizeof(float);
-  size_t lds = (size_t)(kWNP * 8 + kWPZ * 16 * 16 * kWSV) * sizeof(float);
+  const size_t xbytes = (size_t)4 * 2 * tz * nr * 4 * 64 * sizeof(float);
+  size_t lds = (size_t)((tz + 2) * kWPY * kWPX * 8 + (tz + 2) * 16 * 16 * kWSV) * sizeof(float);
   if (lds < xbytes) lds = xbytes;
   lds += (a.in_stats ? (size_t)2 * a.cin_p : 0) * sizeof(float);
   JH_REQUIRE(lds <= 160 * 1024, "wino LDS");
-  if (nr == 3) return launch_wino_nr<3>(a, grid, lds, s);
-  if (nr == 2) return launch_wino_nr<2>(a, grid, lds, s);
-  return launch_wino_nr<1>(a, grid, lds, s);
+#define JH_WINO_CASE(NRV) \
+  if (nr == NRV) return tz == 4 ? launch_wino_nr<NRV, 4>(a, grid, lds, s) : launch_wino_nr<NRV, 2>(a, grid, lds, s);
+  JH_WINO_CASE(3) JH_WINO_CASE(2) JH_WINO_CASE(1)
+#undef JH_WINO_CASE
+  JH_REQUIRE(false, "wino NR");
 }
 
 }  // namespace jh
