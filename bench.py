@@ -216,6 +216,17 @@ def main():
                                 "frac": by / avg_s / 1e9 / PEAK_HBM_GBS, "traffic": None,
                                 "avg_launch_ms": ms / cnt, "launches_per_step": cnt // 3,
                                 "share_of_step": ms / total_ms}
+        if "wino" in name:
+            # Winograd F(2x2,3x3) over (y,x) x direct z executes 12 instead of 27 multiplies per
+            # output and channel pair; `achieved` above is the ALGORITHMIC (direct-convolution)
+            # rate, so it may exceed the MFMA peak.  The matrix cores' own utilisation:
+            cin, cout = [int(v) for v in name.split("_")[2].split("@")[0].split("x")]
+            pad = ((cin + 7) // 8 * 8) * ((cout + 15) // 16 * 16) / float(cin * cout)
+            ex = line["roofline"]["achieved"] * 12.0 / 27.0 * pad
+            line["roofline"]["algorithm"] = ("Winograd F(2x2,3x3) x 3 z taps: 2.25x fewer multiplies than "
+                                             "the direct algorithm `achieved` is counted in")
+            line["roofline"]["mfma_executed"] = {"achieved": ex, "unit": "TFLOP/s",
+                                                 "frac": ex / PEAK_F32_MFMA_TFLOPS}
         # HBM bytes of that kernel from the committed PMC passes (rocprofv3 cannot run
         # inside this process), scaled to this run's time batch
         try:

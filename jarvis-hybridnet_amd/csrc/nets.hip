@@ -126,7 +126,7 @@ int Plan::add_conv(const ParamMap& pm, const ConvDesc& d, const std::string& wke
   const double bytes = 4.0 * ((double)x.N * x.pixels() * d.cin + opix * d.cout + (double)d.cin * d.cout * taps);
   char nm[96];
   snprintf(nm, sizeof nm, "conv%dd_k%ds%d%s_%dx%d@%d", d.nd, d.ostride > 1 ? (d.nd == 2 ? 4 : 2) : d.k,
-           d.ostride > 1 ? 2 : d.stride, d.ostride > 1 ? "T" : "", d.cin, d.cout, y.W);
+           d.ostride > 1 ? 2 : d.stride, d.ostride > 1 ? "T" : (wino ? "wino" : ""), d.cin, d.cout, y.W);
   push(nm, flops, bytes,
        [this, d, cw, x, y, gate, want_stats, off, in_stats_off, in_inv, in_act, wino](hipStream_t s) {
     InNorm in;
