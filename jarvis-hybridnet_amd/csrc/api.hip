@@ -2,6 +2,7 @@
 #include <cstring>
 #include <memory>
 #include "../../include/jarvis_hip.h"
+#include <cstdlib>
 #include "nets.h"
 
 namespace jh {
@@ -521,8 +522,15 @@ int jh_op_conv(int nd, int kind, int k, int stride, int pad, int cin, int cout,
   conv_out_shape(desc, d, h, w, &Do, &Ho, &Wo);
   if (sc.act(n, Do, Ho, Wo, cout, &y)) return 1;
   JH_CHECK_HIP(hipMemsetAsync(y.p, 0, y.bytes(), s));
+  // the same choice the V2V plan makes: 3x3x3 stride-1 convs run as Winograd (JH_WINO=0: direct)
+  bool wino = kind == 0 && nd == 3 && k == 3 && stride == 1 && pad == 1 && !gate_dev;
+  if (const char* e = getenv("JH_WINO")) wino = wino && atoi(e) != 0;
   ConvWeights cw;
-  if (pack_conv_weights(desc, w_host, b_host, kind != 0, &cw)) return 1;
+  if (wino) {
+    if (pack_wino_weights(cin, cout, w_host, b_host, &cw)) return 1;
+  } else {
+    if (pack_conv_weights(desc, w_host, b_host, kind != 0, &cw)) return 1;
+  }
   double* stats = nullptr;
   float* gate_p = nullptr;
   int rc = 0;
@@ -538,7 +546,8 @@ int jh_op_conv(int nd, int kind, int k, int stride, int pad, int cin, int cout,
                            cin * sizeof(float), n, hipMemcpyDeviceToDevice, s) != hipSuccess) { rc = 1; break; }
     }
     if ((rc = launch_to_channel_last(x_dev, x, s))) break;
-    if ((rc = launch_conv(desc, cw, x, y, gate_p, stats, s))) break;
+    if (wino) { if ((rc = launch_conv3d_wino(cw, x, y, stats, s, nullptr))) break; }
+    else if ((rc = launch_conv(desc, cw, x, y, gate_p, stats, s))) break;
     if (norm_act >= 0 && (rc = launch_norm_apply(y, stats, 1e-5f, norm_act, nullptr, nullptr, y.p, nullptr, s))) break;
     if ((rc = launch_from_channel_last(y, y_dev, s))) break;
     if (hipStreamSynchronize(s) != hipSuccess) { set_error("stream sync failed in jh_op_conv"); rc = 1; }
