@@ -53,7 +53,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--time-batch", type=int, default=32, help="multi-view frames per step")
+    ap.add_argument("--time-batch", type=int, default=64, help="multi-view frames per step and GPU")
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--exchange", default="alltoall", choices=["alltoall", "allgather"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
