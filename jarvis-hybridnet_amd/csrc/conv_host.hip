@@ -127,17 +127,17 @@ static int pick_nr(int nb) {
 
 int launch_conv(const ConvDesc& d, const ConvWeights& w, const Act& x, const Act& y,
                 const float* gate, double* stats, hipStream_t s, const InNorm* in) {
-  JH_REQUIRE(x.Cp == w.cin_p, "conv input channel padding mismatch");
+  JH_REQUIRE(x.Cp == w.cin_p || (x.Cp == 4 && w.cin_p == 8), "conv input channel padding mismatch");
   JH_REQUIRE(y.Cp == cpad(d.cout), "conv output channel padding mismatch");
   JH_REQUIRE(x.N == y.N, "batch mismatch");
   ConvArgs a{};
   a.x = x.p; a.y = y.p; a.w = w.w; a.bias = w.bias; a.gate = gate; a.stats = stats;
   if (in && in->stats) {
     a.in_stats = in->stats; a.in_inv = in->inv; a.in_act = in->act;
-    a.nrm_floats = 2 * x.Cp;                 // multiple of 16 floats
+    a.nrm_floats = 2 * w.cin_p;              // multiple of 16 floats
   }
-  if (gate) a.nrm_floats += x.Cp;            // the gate vector of the image, behind mean / rstd
-  a.N = x.N; a.Din = x.D; a.Hin = x.H; a.Win = x.W; a.cin_p = x.Cp;
+  if (gate) a.nrm_floats += w.cin_p;            // the gate vector of the image, behind mean / rstd
+  a.N = x.N; a.Din = x.D; a.Hin = x.H; a.Win = x.W; a.cin_p = w.cin_p; a.in_px = x.Cp;
   a.Dy = y.D; a.Hy = y.H; a.Wy = y.W; a.cout_p = y.Cp; a.cout_p16 = w.cout_p16;
   a.ostride = d.ostride; a.nphase = d.nphase; a.phase_stride = w.phase_stride;
   for (int p = 0; p < d.nphase; ++p) a.phase[p] = d.phase[p];

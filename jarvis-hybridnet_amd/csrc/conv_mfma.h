@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   if (a.gate)
     for (int c = tid; c < a.cin_p; c += 256) gate_l[c] = a.gate[(size_t)n * a.cin_p + c];
 
-  const float* __restrict__ xin = a.x + (size_t)n * a.Din * a.Hin * a.Win * a.cin_p;
+  const float* __restrict__ xin = a.x + (size_t)n * a.Din * a.Hin * a.Win * a.in_px;
   const int nkc8_total = a.cin_p >> 3;
   const int nb16_total = a.cout_p16 >> 4;
   // per-lane weight base; column blocks past the end are clamped (their results are
@@ -231,8 +231,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     const int pz = pix / (G::PX * G::PY);
     const int iz = iz0 + pz, iy = iy0 + py, ix = ix0 + px;
     const int c = c0 + c4 * 4;
-    *src = xin + ((size_t)(iz * a.Hin + iy) * a.Win + ix) * a.cin_p + c;
-    return idx < G::NPIX * Q4 && c < a.cin_p && iz >= 0 && iz < a.Din && iy >= 0 && iy < a.Hin &&
+    *src = xin + ((size_t)(iz * a.Hin + iy) * a.Win + ix) * a.in_px + c;
+    return idx < G::NPIX * Q4 && c < a.in_px && iz >= 0 && iz < a.Din && iy >= 0 && iy < a.Hin &&
            ix >= 0 && ix < a.Win;
   };
   auto finish = [&](float4 v, int c) -> float4 {       // in-range pixels only

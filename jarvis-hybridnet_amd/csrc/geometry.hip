@@ -31,7 +31,7 @@ __device__ __forceinline__ float frame_px(const void* frames, size_t n, int c, i
   return __fmul_rn((float)p[2 - c], __fdiv_rn(1.f, 255.f));
 }
 
-// out: [N][S][S][8] channel-last.
+// out: [N][S][S][4] channel-last (one float4 per pixel: r, g, b, 0).
 template <int SRC>
 __global__ __launch_bounds__(256) void preprocess_resize_kernel(
     const void* __restrict__ frames, float* __restrict__ out, int N, int H, int W, int S,
@@ -57,9 +57,7 @@ __global__ __launch_bounds__(256) void preprocess_resize_kernel(
       const float v = __fmaf_rn(a, ly0, __fmul_rn(b, ly1));
       r[c] = __fdiv_rn(__fsub_rn(v, mv[c]), sv[c]);
     }
-    float4* o = reinterpret_cast<float4*>(out + i * 8);
-    o[0] = make_float4(r[0], r[1], r[2], 0.f);
-    o[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(out + i * 4) = make_float4(r[0], r[1], r[2], 0.f);
   }
 }
 
@@ -79,7 +77,7 @@ int launch_preprocess_resize(const void* frames, int src_u8, float* out, int N, 
   return 0;
 }
 
-// frames: [T][Cloc] images; center_hm: [T][C][2] (all cameras); out [T*Cloc][B][B][8]
+// frames: [T][Cloc] images; center_hm: [T][C][2] (all cameras); out [T*Cloc][B][B][4]
 template <int SRC>
 __global__ __launch_bounds__(256) void preprocess_crop_kernel(
     const void* __restrict__ frames, const int* __restrict__ center_hm, float* __restrict__ out,
@@ -101,9 +99,7 @@ __global__ __launch_bounds__(256) void preprocess_crop_kernel(
       const float v = ok ? frame_px<SRC>(frames, n, c, iy, ix, H, W) : 0.f;
       r[c] = __fdiv_rn(__fsub_rn(v, mv[c]), sv[c]);
     }
-    float4* o = reinterpret_cast<float4*>(out + i * 8);
-    o[0] = make_float4(r[0], r[1], r[2], 0.f);
-    o[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(out + i * 4) = make_float4(r[0], r[1], r[2], 0.f);
   }
 }
 

@@ -106,6 +106,8 @@ struct ConvArgs {
   int Dy, Hy, Wy, cout_p;  // physical output tensor extent
   int cout_p16;
   int kc;                // input channels staged per LDS pass (multiple of 8)
+  int in_px;             // floats per input pixel in memory: cin_p, or 4 for the 3-channel network
+                         // input (one float4 per pixel; channels 4.. of the K padding read 0)
   int ostride, nphase;
   size_t phase_stride;
   ConvPhase phase[8];

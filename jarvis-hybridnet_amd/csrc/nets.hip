@@ -372,6 +372,7 @@ int EffTrackPlan::build(const ParamMap& pm, const std::string& pre, int size, in
   trunk(size, &stem, &blocks, taps);
 
   if (new_act(N, 1, H, W, 3, &input)) return 1;
+  input.Cp = 4;          // one float4 per pixel; the stem conv zero-fills its K padding while staging
   // stem conv + IN + swish (efficientnet.py:150-152, model.py:536-538)
   Ref x;
   if (new_act(N, 1, H / 2, W / 2, stem, &x.a)) return 1;
