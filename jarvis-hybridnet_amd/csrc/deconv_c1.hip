@@ -53,24 +53,51 @@ __global__ __launch_bounds__(256) void deconv_c1_kernel(
   }
   __syncthreads();
   const float* xin = x + (size_t)n * H * W * Cp;
-  for (int idx = tid; idx < kDcPY * kDcPX * q; idx += 256) {
-    const int c4 = idx % q, pix = idx / q;
-    const int iy = y0 - 1 + pix / kDcPX, ix = x0 - 1 + pix % kDcPX;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-      v = *reinterpret_cast<const float4*>(xin + ((size_t)iy * W + ix) * Cp + c4 * 4);
-      const float4 mu = *reinterpret_cast<const float4*>(nrm + c4 * 4);
-      const float4 rs = *reinterpret_cast<const float4*>(nrm + Cp + c4 * 4);
-      v.x = (v.x - mu.x) * rs.x; v.y = (v.y - mu.y) * rs.y;
-      v.z = (v.z - mu.z) * rs.z; v.w = (v.w - mu.w) * rs.w;
-      if (in_act == ACT_RELU) {
-        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-      } else if (in_act == ACT_SILU) {
-        v.x = __fdividef(v.x, 1.f + __expf(-v.x)); v.y = __fdividef(v.y, 1.f + __expf(-v.y));
-        v.z = __fdividef(v.z, 1.f + __expf(-v.z)); v.w = __fdividef(v.w, 1.f + __expf(-v.w));
+  // halo tile: thread -> (channel quad tid % 16, pixel slot tid / 16), compile-time trip count,
+  // the loads of a batch issued before the first LDS store
+  {
+    constexpr int NPX = kDcPY * kDcPX, ITERS = (NPX + 15) / 16, UB = 6;
+    const int slot = tid >> 4;
+   for (int cq0 = 0; cq0 < q; cq0 += 16) {       // 16 channel quads at a time (one for cin <= 64)
+    const int lc4 = cq0 + (tid & 15);
+    const bool cact = lc4 < q;
+    float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), rs = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (cact) {
+      mu = *reinterpret_cast<const float4*>(nrm + lc4 * 4);
+      rs = *reinterpret_cast<const float4*>(nrm + Cp + lc4 * 4);
+    }
+#pragma unroll
+    for (int it0 = 0; it0 < ITERS; it0 += UB) {
+      float4 v[UB];
+      bool ok[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int pix = (it0 + u) * 16 + slot;
+        const int iy = y0 - 1 + pix / kDcPX, ix = x0 - 1 + pix % kDcPX;
+        ok[u] = it0 + u < ITERS && pix < NPX && cact && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        v[u] = ok[u] ? *reinterpret_cast<const float4*>(xin + ((size_t)iy * W + ix) * Cp + lc4 * 4)
+                     : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int pix = (it0 + u) * 16 + slot;
+        if (it0 + u < ITERS && pix < NPX && cact) {
+          float4 x4 = v[u];
+          if (ok[u]) {
+            x4.x = (x4.x - mu.x) * rs.x; x4.y = (x4.y - mu.y) * rs.y;
+            x4.z = (x4.z - mu.z) * rs.z; x4.w = (x4.w - mu.w) * rs.w;
+            if (in_act == ACT_RELU) {
+              x4.x = fmaxf(x4.x, 0.f); x4.y = fmaxf(x4.y, 0.f); x4.z = fmaxf(x4.z, 0.f); x4.w = fmaxf(x4.w, 0.f);
+            } else if (in_act == ACT_SILU) {
+              x4.x = __fdividef(x4.x, 1.f + __expf(-x4.x)); x4.y = __fdividef(x4.y, 1.f + __expf(-x4.y));
+              x4.z = __fdividef(x4.z, 1.f + __expf(-x4.z)); x4.w = __fdividef(x4.w, 1.f + __expf(-x4.w));
+            }
+          }
+          *reinterpret_cast<float4*>(tile + pix * S + lc4 * 4) = x4;
+        }
       }
     }
-    *reinterpret_cast<float4*>(tile + pix * S + c4 * 4) = v;
+   }
   }
   __syncthreads();
 

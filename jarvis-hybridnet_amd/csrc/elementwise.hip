@@ -177,14 +177,31 @@ __global__ __launch_bounds__(256) void depthwise_lds_kernel(
   const int n = bid.z;
   const int q = min(CC, Cp - c0) >> 2;             // channel quads in this chunk (<= 8)
   const float* xin = x + (size_t)n * H * W * Cp;
-  for (int idx = tid; idx < HT * HT * q; idx += 256) {
-    const int c4 = idx % q, pix = idx / q;
-    const int px = pix % HT, py = pix / HT;
-    const int iy = oy0 + py - K / 2, ix = ox0 + px - K / 2;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (iy >= 0 && iy < H && ix >= 0 && ix < W)
-      v = *reinterpret_cast<const float4*>(xin + ((size_t)iy * W + ix) * Cp + c0 + c4 * 4);
-    *reinterpret_cast<float4*>(sm + pix * SP + c4 * 4) = v;
+  // halo patch: thread -> (channel quad tid % 8, pixel slot tid / 8); the loop has a
+  // compile-time trip count and all loads of a batch are issued before the first LDS store
+  // (a load -> store loop with a run-time bound kept ONE load in flight per thread and
+  // cost ~25 us per workgroup)
+  {
+    constexpr int NPX = HT * HT, ITERS = (NPX + 31) / 32, UB = 7;
+    const int lc4 = tid & 7, slot = tid >> 3;
+#pragma unroll
+    for (int it0 = 0; it0 < ITERS; it0 += UB) {
+      float4 v[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int pix = (it0 + u) * 32 + slot;
+        const int px = pix % HT, py = pix / HT;
+        const int iy = oy0 + py - K / 2, ix = ox0 + px - K / 2;
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (it0 + u < ITERS && pix < NPX && lc4 < q && iy >= 0 && iy < H && ix >= 0 && ix < W)
+          v[u] = *reinterpret_cast<const float4*>(xin + ((size_t)iy * W + ix) * Cp + c0 + lc4 * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int pix = (it0 + u) * 32 + slot;
+        if (it0 + u < ITERS && pix < NPX && lc4 < q) *reinterpret_cast<float4*>(sm + pix * SP + lc4 * 4) = v[u];
+      }
+    }
   }
   const int c4 = tid & 7;                          // fixed channel quad of this thread
   const bool active = c4 < q;

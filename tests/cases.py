@@ -19,6 +19,13 @@ EFFTRACK_CASES = {
     "large_j23": ("large", 23, 1, 192, 9, 10),
 }
 
+# GPU-only cases (checked against the oracle run on the host, no fixture): the one-channel
+# CenterDetect head on the wider pyramids of the medium / large models
+EFFTRACK_GPU_CASES = {
+    "medium_j1": ("medium", 1, 2, 256, 11, 12),
+    "large_j1": ("large", 1, 1, 192, 13, 14),
+}
+
 # tag -> (C, J, G, spacing, bbox, W, H, focal, seed)
 REPRO_CASES = {
     "tiny": (2, 3, 8, 4, 28, 160, 128, 300.0, 11),

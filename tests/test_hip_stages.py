@@ -16,12 +16,12 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("tag", ["cfg1_small_j12", "small_j1_b2", "small_j23_b2", "small_j23_128",
-                                 "medium_j23", "large_j23"])
+                                 "medium_j23", "large_j23", "medium_j1", "large_j1"])
 def test_efficienttrack(tag):
     from jarvis_hybridnet_amd import synthetic as S
     from jarvis_hybridnet_amd.efficienttrack.model import EfficientTrackBackbone
     from oracle import hybridnet_oracle as O
-    size, J, N, hw, wseed, xseed = cases.EFFTRACK_CASES[tag]
+    size, J, N, hw, wseed, xseed = {**cases.EFFTRACK_CASES, **cases.EFFTRACK_GPU_CASES}[tag]
     sd = S.efficienttrack_weights(size, J, wseed)
     x = cases.efftrack_input(N, hw, xseed)
     with torch.no_grad():
