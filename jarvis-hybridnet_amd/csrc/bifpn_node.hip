@@ -119,26 +119,24 @@ __global__ __launch_bounds__(512, 6) void bifpn_node_kernel(const NodeArgs a) {
   const int nk8 = Cp >> 3, nb = a.cout_p16 >> 4;
   const float2* wl = reinterpret_cast<const float2*>(a.pw) + lane;
 
-  // 1. depthwise weights and statistics -> mean / rstd (biased variance, eps 1e-5)
-  for (int i = tid; i < 9 * Cp; i += NT) dwl[i] = a.dw[i];
-  for (int i = tid; i < a.n_in * Cp; i += NT) {
-    const int k = i / Cp, c = i % Cp;
-    float mean = 0.f, rstd = 1.f;
-    if (a.st[k]) {
-      const double* st = a.st[k] + ((size_t)n * Cp + c) * 2;
-      const double mu = st[0] * (double)a.inv_cnt[k];
-      double var = st[1] * (double)a.inv_cnt[k] - mu * mu;
-      if (var < 0.0) var = 0.0;
-      mean = (float)mu;
-      rstd = (float)(1.0 / sqrt(var + 1e-5));
-    }
-    mr_[k * Cp + c] = mean;
-    mr_[3 * Cp + k * Cp + c] = rstd;
-  }
-  __syncthreads();
-
-  // 2. fused halo tile -> depthwise -> operand tile
+  // 1 + 2. statistics -> mean / rstd, fused halo tile -> depthwise -> operand tile
   if constexpr (ONE) {
+    // The statistics (and depthwise weights) are requested FIRST and consumed after the first
+    // batch of halo loads has been issued (loads return in order): the mean / rstd round trip
+    // runs under the halo round trip instead of in front of it.
+    double sv0 = 0.0, sv1 = 0.0;
+    bool has_st = false;
+    const int sk = tid / Cp, scn = tid - sk * Cp;        // launcher: n_in * Cp <= 512
+    if (tid < a.n_in * Cp && a.st[sk]) {
+      const double* st = a.st[sk] + ((size_t)n * Cp + scn) * 2;
+      sv0 = st[0];
+      sv1 = st[1];
+      has_st = true;
+    }
+    float dwv[2];                                        // launcher: 9 * Cp <= 1024
+#pragma unroll
+    for (int j = 0; j < 2; ++j) dwv[j] = tid + j * NT < 9 * Cp ? a.dw[tid + j * NT] : 0.f;
+    bool first = true;
     // Single channel chunk (Cp <= 64, operand tile aliased onto the halo tile).  The kernel
     // is bound by vector-ALU issue, the halo phase by its index arithmetic, so this form has
     // none to speak of: thread -> (channel quad c4 = tid % 16, pixel slot tid / 16), pixel
@@ -169,6 +167,25 @@ __global__ __launch_bounds__(512, 6) void bifpn_node_kernel(const NodeArgs a) {
                           : make_float4(0.f, 0.f, 0.f, 0.f);
         px += 32 - kNodePX; py += 1;
         if (px >= kNodePX) { px -= kNodePX; py += 1; }
+      }
+      if (first) {                               // (uniform)
+        first = false;
+        if (tid < a.n_in * Cp) {
+          float mean = 0.f, rstd = 1.f;
+          if (has_st) {                          // biased variance, eps 1e-5
+            const double mu = sv0 * (double)a.inv_cnt[sk];
+            double var = sv1 * (double)a.inv_cnt[sk] - mu * mu;
+            if (var < 0.0) var = 0.0;
+            mean = (float)mu;
+            rstd = (float)(1.0 / sqrt(var + 1e-5));
+          }
+          mr_[sk * Cp + scn] = mean;
+          mr_[3 * Cp + sk * Cp + scn] = rstd;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          if (tid + j * NT < 9 * Cp) dwl[tid + j * NT] = dwv[j];
+        __syncthreads();
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -246,6 +263,24 @@ __global__ __launch_bounds__(512, 6) void bifpn_node_kernel(const NodeArgs a) {
     }
     __syncthreads();
   } else {
+    // 1. depthwise weights and statistics -> mean / rstd (biased variance, eps 1e-5)
+    for (int i = tid; i < 9 * Cp; i += NT) dwl[i] = a.dw[i];
+    for (int i = tid; i < a.n_in * Cp; i += NT) {
+      const int k = i / Cp, c = i % Cp;
+      float mean = 0.f, rstd = 1.f;
+      if (a.st[k]) {
+        const double* st = a.st[k] + ((size_t)n * Cp + c) * 2;
+        const double mu = st[0] * (double)a.inv_cnt[k];
+        double var = st[1] * (double)a.inv_cnt[k] - mu * mu;
+        if (var < 0.0) var = 0.0;
+        mean = (float)mu;
+        rstd = (float)(1.0 / sqrt(var + 1e-5));
+      }
+      mr_[k * Cp + c] = mean;
+      mr_[3 * Cp + k * Cp + c] = rstd;
+    }
+    __syncthreads();
+
     // general form: one channel chunk at a time (models with wider pyramids)
     for (int cf0 = 0; cf0 < Cp; cf0 += a.cf) {
       const int cw = min(a.cf, Cp - cf0);          // multiple of 4
