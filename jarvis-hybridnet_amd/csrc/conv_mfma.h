@@ -263,7 +263,23 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     }
   }
 
+  // BREG: kernels whose whole weight set of a channel pass is small (1x1 convs, narrow 3x3
+  // layers) fetch it into registers at the top of the pass, so the round trip to L2 runs under
+  // the patch commit and the barriers instead of in front of every tap.
+  constexpr bool PIPE = (G::NT > 1) && (MR * NR * KC8 >= 12);
+  constexpr bool BREG = !PIPE && (G::NT == 1 ? KC8 * NR <= 16 : G::NT * KC8 * NR <= 9);   // (measured)
   for (int c0 = 0; c0 < a.cin_p; c0 += KC) {
+    float2 breg[BREG ? G::NT : 1][KC8][NR];
+    if constexpr (BREG) {
+#pragma unroll
+      for (int tp = 0; tp < G::NT; ++tp)
+#pragma unroll
+        for (int k8 = 0; k8 < KC8; ++k8)
+#pragma unroll
+          for (int nr = 0; nr < NR; ++nr)
+            breg[tp][k8][nr] = (wbase + ulane)[(size_t)tp * tap_stride +
+                                               min((c0 >> 3) + k8, nkc8_total - 1) * nb16_total * 64 + boff[nr]];
+    }
     __syncthreads();
     // ---- stage the halo patch: [pixel][KC] with stride S; channels past cin_p read 0
     if constexpr (PF) {
@@ -307,7 +323,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     // Two forms of the tap loop.  PIPE (kernels with enough matrix work per tap): explicit
     // one-tap-ahead operand prefetch with a prescribed issue order.  Otherwise (1x1 convs,
     // narrow layers) the plain loop, which the compiler schedules better on its own.
-    constexpr bool PIPE = (G::NT > 1) && (MR * NR * KC8 >= 12);
     if constexpr (PIPE) {
       // ---- taps: all KC8 8-channel steps of a tap are unrolled.  BOTH operands of tap t+1
       // (A rows from LDS, B columns from L2) are requested while the MFMAs of tap t issue,
@@ -383,6 +398,31 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
               if (REM > 0) __builtin_amdgcn_sched_group_barrier(0x008, REM, 0);
             }
           }
+        }
+      }
+    } else if constexpr (BREG) {
+      // ---- taps with register-resident weights: only LDS reads and MFMAs in the loop
+#pragma unroll
+      for (int tp = 0; tp < G::NT; ++tp) {
+        const int dz = tp / (G::KH * G::KW), dy = (tp / G::KW) % G::KH, dx = tp % G::KW;
+        const int toff = ((dz * G::PY + dy) * G::PX + dx) * S2;
+        float2 ac[KC8][MR];
+#pragma unroll
+        for (int k8 = 0; k8 < KC8; ++k8)
+#pragma unroll
+          for (int mr = 0; mr < MR; ++mr) ac[k8][mr] = lds2[abase[mr] + toff + k8 * 4];
+#pragma unroll
+        for (int k8 = 0; k8 < KC8; ++k8) {
+#pragma unroll
+          for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr)
+              acc[mr][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[k8][mr].x, breg[tp][k8][nr].x, acc[mr][nr], 0, 0, 0);
+#pragma unroll
+          for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr)
+              acc[mr][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[k8][mr].y, breg[tp][k8][nr].y, acc[mr][nr], 0, 0, 0);
         }
       }
     } else {
