@@ -436,8 +436,11 @@ int EffTrackPlan::build(const ParamMap& pm, const std::string& pre, int size, in
     { const Ref in[2] = {p3_in, p4_up}; if (fnode("p3_w1", 2, in, m_up, p3_in, "conv3_up", &p3_out)) return 1; }
     { const Ref in[3] = {p4_in2, p4_up, p3_out}; if (fnode("p4_w2", 3, in, m_dn3, p4_in2, "conv4_down", &p4_out)) return 1; }
     { const Ref in[3] = {p5_in2, p5_up, p4_out}; if (fnode("p5_w2", 3, in, m_dn3, p5_in2, "conv5_down", &p5_out)) return 1; }
-    { const Ref in[3] = {p6_in, p6_up, p5_out}; if (fnode("p6_w2", 3, in, m_dn3, p6_in, "conv6_down", &p6_out)) return 1; }
-    { const Ref in[2] = {p7_in, p6_out}; if (fnode("p7_w2", 2, in, m_dn2, p7_in, "conv7_down", &p7_out)) return 1; }
+    // the head reads p3, p4, p5 of the last cell only: its p6 / p7 outputs are dead
+    if (cell + 1 < ss.cells) {
+      { const Ref in[3] = {p6_in, p6_up, p5_out}; if (fnode("p6_w2", 3, in, m_dn3, p6_in, "conv6_down", &p6_out)) return 1; }
+      { const Ref in[2] = {p7_in, p6_out}; if (fnode("p7_w2", 2, in, m_dn2, p7_in, "conv7_down", &p7_out)) return 1; }
+    }
     p3 = p3_out; p4 = p4_out; p5 = p5_out; p6 = p6_out; p7 = p7_out;
   }
 
