@@ -220,3 +220,37 @@ def test_predict3d_frames_writes_csv(tmp_path, golden):
     n = predict3D_frames(pred, [u8, u8, u8], *dev, cfg, str(tmp_path / "tb"), time_batch=2)
     rows2 = list(csv.reader(open(tmp_path / "tb" / "data3D.csv")))
     assert n == 3 and len(rows2) == 5 and rows2[2] == rows2[3] == rows2[4] == rows[3]
+
+
+def test_error_paths_are_loud():
+    """No silent fallbacks: bad inputs surface as exceptions carrying the library's message
+    (jh_last_error), as the reference's own failures surface as exceptions."""
+    from jarvis_hybridnet_amd import _native as N
+    from jarvis_hybridnet_amd import synthetic as S
+    from jarvis_hybridnet_amd.efficienttrack.model import EfficientTrackBackbone
+    from jarvis_hybridnet_amd.hybridnet.v2vnet import V2VNet
+    # image side that is not a multiple of 64
+    net = EfficientTrackBackbone(None, "small", 3)
+    net.load_state_dict(S.efficienttrack_weights("small", 3, 1), strict=True)
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        net(torch.zeros(1, 3, 100, 100, device="cuda"))
+    # CPU tensors are rejected, not copied
+    with pytest.raises(RuntimeError, match="needs CUDA"):
+        net(torch.zeros(1, 3, 128, 128))
+    # a state dict with a missing key
+    sd = S.v2v_weights(3, 2)
+    sd.pop(sorted(sd)[0])
+    v = V2VNet(3, 3)
+    with pytest.raises((RuntimeError, KeyError)):
+        v.load_state_dict(sd, strict=True)
+        v(torch.zeros(1, 3, 16, 16, 16, device="cuda"))
+    # grid side that V2V cannot halve twice
+    v2 = V2VNet(3, 3)
+    v2.load_state_dict(S.v2v_weights(3, 2), strict=True)
+    with pytest.raises(RuntimeError, match="multiple of 4"):
+        v2(torch.zeros(1, 3, 18, 18, 18, device="cuda"))
+    # after an error the library keeps working
+    y = v2(torch.rand(1, 3, 16, 16, 16, device="cuda"))
+    torch.cuda.synchronize()
+    assert y.shape == (1, 3, 8, 8, 8) and bool(torch.isfinite(y).all())
+    assert N.lib().jh_abi_version() >= 1
