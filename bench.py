@@ -53,7 +53,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--time-batch", type=int, default=64, help="multi-view frames per step and GPU")
+    ap.add_argument("--time-batch", type=int, default=None,
+                    help="multi-view frames per time batch (default: 32 per stream on one GPU, 64 per "
+                         "GPU when camera-sharded)")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="single GPU: independent time batches in flight on that many HIP streams; one "
+                         "step = one time batch per stream")
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--exchange", default="alltoall", choices=["alltoall", "allgather"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -89,6 +94,9 @@ def main():
     from jarvis_hybridnet_amd._predictor import NativePredictor
 
     c = CONFIGS[args.config]
+    if args.time_batch is None:
+        args.time_batch = 64 if sharded else 32
+    K = 1 if (sharded or args.graph) else max(1, args.streams)
     # Weak scaling: every rank always does the work of `--time-batch` whole frames
     # (T*C images of 2D work, T frames of 3D work).  Ranks form groups of `gs` GPUs
     # that shard the cameras of T*gs frames; world/gs groups run side by side.
@@ -112,14 +120,23 @@ def main():
                   roi_cube_size=c["roi"], grid_spacing=c["spacing"], img_h=c["H"], img_w=c["W"],
                   mean=S.MEAN, std=S.STD, time_batch=T)
     if not sharded:
-        pred = NativePredictor(sd_c, sd_h, **common)
-        pred.set_calibration(*[t.to(dev) for t in calib])
+        from jarvis_hybridnet_amd._predictor import MultiStreamPredictor
+        msp = MultiStreamPredictor(lambda: NativePredictor(sd_c, sd_h, **common), streams=K)
+        msp.set_calibration(*[t.to(dev) for t in calib])
+        pred = msp.preds[0]                        # the per-kernel profile and the side legs use one
         fr = device_frames(0, c["C"])
-        out = (torch.empty((T, c["J"], 3), device=dev), torch.empty((T, c["J"]), device=dev),
-               torch.empty((T,), device=dev, dtype=torch.int32))
+        outs = [(torch.empty((T, c["J"], 3), device=dev), torch.empty((T, c["J"]), device=dev),
+                 torch.empty((T,), device=dev, dtype=torch.int32)) for _ in range(K)]
+        out = outs[0]
+        torch.cuda.synchronize()
 
         def step():
-            return pred.forward(fr, out)
+            # one step = one time batch per stream (K * T frame sets)
+            res0 = None
+            for i in range(K):
+                r = msp.forward(fr, outs[i]) if K > 1 else pred.forward(fr, outs[i])
+                res0 = r if i == 0 else res0
+            return res0
     else:
         from jarvis_hybridnet_amd.distributed import ShardedPredictor, camera_range
         groups = [dist.new_group(list(range(g * gs, (g + 1) * gs))) for g in range(n_groups)]
@@ -170,7 +187,7 @@ def main():
     torch.cuda.synchronize()
     res = [r.clone() if torch.is_tensor(r) else r for r in res]      # `out` is reused below
     valid = int(res[2].sum().item())
-    fps = T * n_groups * args.steps / dt
+    fps = T * K * n_groups * args.steps / dt
 
     line = {
         "metric": "multi-view frames/s (12cam 1280x1024, 23kpt, 64^3 grid)",
@@ -181,20 +198,22 @@ def main():
         "config": {"workload": "BASELINE configs[2]: HybridNet 12-camera 1280x1024, 23 kpts, "
                                "64^3 grid, small/small" if args.config == "cfg3" else args.config,
                    "cameras": c["C"], "frame": [c["H"], c["W"]], "joints": c["J"],
-                   "grid": int(c["roi"] / c["spacing"]), "time_batch": T,
-                   "frames_per_step": T * n_groups, "valid_frames_last_step": valid,
-                   "parallelism": "single GPU" if not sharded else
+                   "grid": int(c["roi"] / c["spacing"]), "time_batch": T, "streams": K,
+                   "frames_per_step": T * K * n_groups, "valid_frames_last_step": valid,
+                   "parallelism": ("single GPU, %d time batches in flight on %d HIP streams" % (K, K))
+                   if not sharded else
                    "%d group(s) x %d GPUs: camera-sharded 2D (%d cams/GPU) + RCCL %s of "
                    "heatmaps%s + frame-sharded 3D" % (n_groups, gs, c["C"] // gs, args.exchange,
                                                        "" if args.no_pipeline else " (overlapped with the next step's CenterDetect)"),
-                   "launches_per_step": int(pred.launches), "hipgraph": bool(args.graph)},
+                   "launches_per_step": int(pred.launches) * K, "launches_per_time_batch": int(pred.launches),
+                   "hipgraph": bool(args.graph)},
     }
 
     if rank == 0 and not sharded:
         # ---- roofline of the dominant kernel, HIP events around every launch
         recs = []
         for _ in range(3):
-            recs += N.profile(step)
+            recs += N.profile(step if sharded else (lambda: pred.forward(fr, out)))   # one stream: kernels timed alone
         agg = {}
         for name, ms, fl, by in recs:
             a = agg.setdefault(name, [0.0, 0, fl, by])

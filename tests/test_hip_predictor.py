@@ -254,3 +254,31 @@ def test_error_paths_are_loud():
     torch.cuda.synchronize()
     assert y.shape == (1, 3, 8, 8, 8) and bool(torch.isfinite(y).all())
     assert N.lib().jh_abi_version() >= 1
+
+
+def test_multi_stream_predictor_equals_single_stream():
+    """MultiStreamPredictor (K independent time batches in flight on K HIP streams, one plan
+    set each) returns, batch for batch, what a single predictor returns."""
+    from jarvis_hybridnet_amd._predictor import MultiStreamPredictor, NativePredictor
+    from jarvis_hybridnet_amd import synthetic as S
+    c = cases.PREDICTOR_CASES["cfg2"]
+    inp = cases.predictor_inputs("cfg2")
+    kw = dict(num_cameras=c["C"], num_joints=c["J"], center_size=c["center_size"], bbox=c["bbox"],
+              roi_cube_size=c["roi"], grid_spacing=c["spacing"], img_h=c["H"], img_w=c["W"],
+              mean=S.MEAN, std=S.STD, time_batch=2)
+    calib = [cuda(inp[k]) for k in ("cam", "intr", "dist")]
+    single = NativePredictor(inp["sd_center"], inp["sd_hybrid"], **kw)
+    single.set_calibration(*calib)
+    msp = MultiStreamPredictor(lambda: NativePredictor(inp["sd_center"], inp["sd_hybrid"], **kw), streams=3)
+    msp.set_calibration(*calib)
+    imgs = cuda(inp["imgs"])
+    batches = [torch.stack([imgs, imgs.flip(0)]), torch.stack([imgs.flip(0), imgs]),
+               torch.stack([imgs, imgs]), torch.stack([imgs.roll(1, 0), imgs])]
+    got = [msp.forward(b) for b in batches]            # 4 batches over 3 streams: stream 0 is reused
+    msp.synchronize()
+    got = [[t.clone() for t in g] for g in got[1:]]    # batch 0's buffers were not reused (own `out`)
+    for b, g in zip(batches[1:], got):
+        ref = single.forward(b)
+        torch.cuda.synchronize()
+        for x, y in zip(g, ref):
+            assert torch.equal(x, y)
