@@ -21,7 +21,7 @@ JP = 8
 KW = dict(center_size=CENTER, bbox=BBOX, roi_cube_size=ROI, grid_spacing=SP, mean=S.MEAN, std=S.STD)
 
 
-def make_inputs():
+def make_inputs(T=T):
     calib = S.ring_calibration(C, W, H, 450.0)
     sd_c = S.efficienttrack_weights("small", 1, 80)
     sd_h = S.hybridnet_weights("small", J, 81)
@@ -89,11 +89,11 @@ class OracleStages:
                 pts[i], conf[i], valid[i] = p[0], cf[0], self.state[("valid", t)]
 
 
-def _worker(rank, world, port, exchange, q):
+def _worker(rank, world, port, exchange, q, T=T):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    calib, sd_c, sd_h, frames = make_inputs()
+    calib, sd_c, sd_h, frames = make_inputs(T)
     lo, n = camera_range(C, rank, world)
     st = OracleStages(calib, sd_c, sd_h, lo, n)
     sh = ShardedPredictor(st, num_cameras=C, num_joints=J, time_batch=T,
@@ -118,21 +118,24 @@ def _worker(rank, world, port, exchange, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange", ["alltoall", "allgather"])
-def test_camera_sharded_equals_single_process(exchange):
+@pytest.mark.parametrize("exchange,world", [("alltoall", 2), ("allgather", 2), ("alltoall", 4)])
+def test_camera_sharded_equals_single_process(exchange, world):
+    """world 4 = one camera per rank, the group size the 4- and 8-GPU runs use (12 cameras -> 3
+    per rank there)."""
+    T = 2 if world == 2 else 4
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, exchange, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, exchange, q, T)) for r in range(world)]
     for p in procs:
         p.start()
     pts, conf, valid = q.get(timeout=240)
     for p in procs:
         p.join(timeout=600)
         assert p.exitcode == 0
-    calib, sd_c, sd_h, frames = make_inputs()
+    calib, sd_c, sd_h, frames = make_inputs(T)
     for t in range(T):
         with torch.no_grad():
             rp, rc = O.predictor3d_forward(sd_c, sd_h, frames[t], *calib, **KW)
