@@ -100,8 +100,8 @@ def main():
     # Weak scaling: every rank always does the work of `--time-batch` whole frames
     # (T*C images of 2D work, T frames of 3D work).  Ranks form groups of `gs` GPUs
     # that shard the cameras of T*gs frames; world/gs groups run side by side.
-    gs = max(d for d in range(1, world + 1) if world % d == 0 and c["C"] % d == 0)
-    n_groups = world // gs
+    from jarvis_hybridnet_amd.distributed import plan_groups
+    gs, n_groups = plan_groups(world, c["C"])
     grank, gidx = rank % gs, rank // gs
     T = args.time_batch * gs                       # frames per group and step
     calib = S.ring_calibration(c["C"], c["W"], c["H"], c["focal"])

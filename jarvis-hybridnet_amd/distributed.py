@@ -30,6 +30,14 @@ import torch
 import torch.distributed as dist
 
 
+def plan_groups(world, num_cameras):
+    """Ranks form groups of `gs` GPUs that shard the cameras of a time batch; world // gs such
+    groups run side by side on different frames.  gs = the largest divisor of the world size
+    that divides the camera count (12 cameras: 2 -> 2, 4 -> 4, 8 -> 2 groups of 4)."""
+    gs = max(d for d in range(1, world + 1) if world % d == 0 and num_cameras % d == 0)
+    return gs, world // gs
+
+
 def camera_range(num_cameras, rank, world):
     assert num_cameras % world == 0, "cameras must divide evenly over the ranks"
     n = num_cameras // world

@@ -146,3 +146,17 @@ def test_camera_sharded_equals_single_process(exchange, world):
             # treat images as independent instances, see test_predictor3d_time_batch.)
             assert (pts[t] - rp[0]).abs().max().item() < 1e-3
             assert (conf[t] - rc[0]).abs().max().item() < 1e-5
+
+
+def test_plan_groups():
+    from jarvis_hybridnet_amd.distributed import plan_groups, frame_range
+    assert plan_groups(1, 12) == (1, 1)
+    assert plan_groups(2, 12) == (2, 1)
+    assert plan_groups(4, 12) == (4, 1)
+    assert plan_groups(8, 12) == (4, 2)          # 12 cameras do not divide over 8 GPUs
+    assert plan_groups(8, 16) == (8, 1)
+    assert plan_groups(5, 12) == (1, 5)
+    for w in (1, 2, 4):
+        lo = [camera_range(12, r, w) for r in range(w)]
+        assert sum(n for _, n in lo) == 12 and [a for a, _ in lo] == [r * (12 // w) for r in range(w)]
+        assert [frame_range(64, r, w)[0] for r in range(w)] == [r * (64 // w) for r in range(w)]
