@@ -21,23 +21,10 @@
 #include <cstdlib>
 #include <vector>
 #include "conv_mfma.h"
+#include "conv3d_wino.h"
 
 namespace jh {
 
-struct WinoArgs {
-  const float* x;          // [N][D][H][W][cin_p]
-  float* y;                // [N][D][H][W][cout_p] raw output
-  const float* u;          // transformed weights [16 f][3 dz][cin_p/8][cout_p16/16][64][2]
-  const float* bias;       // [cout_p16] or nullptr
-  const double* in_stats;  // InstanceNorm (+ in_act) of the input applied on load, or nullptr
-  float in_inv;
-  int in_act;
-  double* stats;           // [N][cout_p][2] or nullptr
-  int N, D, H, W, cin_p, cout_p, cout_p16;
-};
-
-constexpr int kWTY = 8, kWTX = 8;                           // (y, x) outputs per workgroup
-constexpr int kWPY = kWTY + 2, kWPX = kWTX + 2;
 constexpr int kWSV = 12;                                    // V row stride (floats): b64 reads of
                                                             // 16 tiles hit 64 distinct banks
 
@@ -390,6 +377,13 @@ int launch_conv3d_wino(const ConvWeights& w, const Act& x, const Act& y, double*
   // resident workgroup does not pay for the doubled per-workgroup prologue / epilogue
   int tz = 4;
   if (const char* e = getenv("JH_WINO_TZ")) tz = atoi(e) == 2 ? 2 : 4;
+  // ping-pong form (conv3d_wino_pp.hip): two wave sets alternating MFMA / transform roles.
+  // Measured: 0.176 vs 0.182 ms per 8 frames alone, but no gain (1616 vs 1608 frames/s) once
+  // three time batches share the GPU -- it takes 137 KB of LDS and 8 waves per CU that the
+  // other streams' kernels could use -- so it is opt-in.
+  bool pp = false;
+  if (const char* e = getenv("JH_WINO_PP")) pp = atoi(e) != 0;
+  if (pp) return launch_conv3d_wino_pp(a, nr, s);
   const int blocks = ((x.D + tz - 1) / tz) * ((x.H + kWTY - 1) / kWTY) * ((x.W + kWTX - 1) / kWTX);
   dim3 grid(blocks, (nb + nr - 1) / nr, x.N);
   const size_t xbytes = (size_t)4 * 2 * tz * nr * 4 * 64 * sizeof(float);

@@ -110,11 +110,14 @@ def test_conv3d_winograd_equals_direct(cin, cout, D, H, W, monkeypatch):
     w = torch.randn(cout, cin, 3, 3, 3, generator=g) / (cin * 27) ** 0.5
     b = torch.randn(cout, generator=g) * 0.1
     y_w, ref = _conv(3, 0, 3, 1, 1, cin, cout, x, w, b, norm_act=1)
+    monkeypatch.setenv("JH_WINO_PP", "1")          # the two-wave-set ("ping-pong") form
+    y_p, _ = _conv(3, 0, 3, 1, 1, cin, cout, x, w, b, norm_act=1)
+    monkeypatch.delenv("JH_WINO_PP")
     monkeypatch.setenv("JH_WINO", "0")
     y_d, _ = _conv(3, 0, 3, 1, 1, cin, cout, x, w, b, norm_act=1)
-    ew, ed = rel_err(y_w, ref), rel_err(y_d, ref)
-    report("conv3d_winograd", cin=cin, cout=cout, rel_winograd=ew, rel_direct=ed)
-    assert ew < 2e-4 and ed < 2e-4
+    ew, ep, ed = rel_err(y_w, ref), rel_err(y_p, ref), rel_err(y_d, ref)
+    report("conv3d_winograd", cin=cin, cout=cout, rel_winograd=ew, rel_pingpong=ep, rel_direct=ed)
+    assert ew < 2e-4 and ep < 2e-4 and ed < 2e-4
     assert not torch.equal(y_w, y_d), "JH_WINO had no effect"
 
 
