@@ -209,8 +209,12 @@ def main():
                    "hipgraph": bool(args.graph)},
     }
 
-    if rank == 0 and not sharded:
-        # ---- roofline of the dominant kernel, HIP events around every launch
+    if sharded and rank != 0:
+        for _ in range(3):                         # rank 0 profiles 3 steps: keep the collectives matched
+            step()
+    if rank == 0:
+        # ---- roofline of the dominant kernel, HIP events around every launch (at N > 1: rank 0's
+        # share of the camera-sharded step)
         recs = []
         for _ in range(3):
             recs += N.profile(step if sharded else (lambda: pred.forward(fr, out)))   # one stream: kernels timed alone
@@ -251,7 +255,7 @@ def main():
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
             if name in pmc:
-                line["roofline"]["traffic"] = pmc[name]["hbm_bytes_per_launch"] * T / pmc[name]["time_batch"]
+                line["roofline"]["traffic"] = pmc[name]["hbm_bytes_per_launch"] * (T // gs if sharded else T) / pmc[name]["time_batch"]
                 line["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
                 line["roofline"]["algorithmic_bytes"] = by
         except (OSError, ValueError):
