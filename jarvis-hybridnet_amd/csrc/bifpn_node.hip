@@ -24,7 +24,6 @@
 
 namespace jh {
 
-constexpr int kNodeTY = 8, kNodeTX = 16, kNodePY = 10, kNodePX = 18, kNodeNRG = 4;
 
 __device__ __forceinline__ float4 node_fetch(const float* in, int mode, int n, int oy, int ox, int H,
                                              int W, int Cp, int c) {
@@ -46,39 +45,6 @@ __device__ __forceinline__ float4 node_fetch(const float* in, int mode, int n, i
   const float4 a3 = *reinterpret_cast<const float4*>(b + (size_t)w * Cp + Cp);
   return make_float4(fmaxf(fmaxf(a0.x, a1.x), fmaxf(a2.x, a3.x)), fmaxf(fmaxf(a0.y, a1.y), fmaxf(a2.y, a3.y)),
                      fmaxf(fmaxf(a0.z, a1.z), fmaxf(a2.z, a3.z)), fmaxf(fmaxf(a0.w, a1.w), fmaxf(a2.w, a3.w)));
-}
-
-// Same, for the single-chunk kernel: `b` is the (uniform) base of image n of the input at
-// ITS resolution, offsets are 32-bit.
-__device__ __forceinline__ float4 node_fetch_n(const float* b, int mode, int oy, int ox, int H, int W,
-                                               int Cp, int c) {
-  if (mode == FUSE_SAME) return *reinterpret_cast<const float4*>(b + ((oy * W + ox) * Cp + c));
-  if (mode == FUSE_UP2)
-    return *reinterpret_cast<const float4*>(b + (((oy >> 1) * (W >> 1) + (ox >> 1)) * Cp + c));
-  if (mode == FUSE_UP4)
-    return *reinterpret_cast<const float4*>(b + (((oy >> 2) * (W >> 2) + (ox >> 2)) * Cp + c));
-  const int w = W * 2;                // FUSE_POOL2 (max commutes with the monotone IN map)
-  const float* s = b + ((oy * 2 * w + ox * 2) * Cp + c);
-  const float4 a0 = *reinterpret_cast<const float4*>(s);
-  const float4 a1 = *reinterpret_cast<const float4*>(s + Cp);
-  const float4 a2 = *reinterpret_cast<const float4*>(s + w * Cp);
-  const float4 a3 = *reinterpret_cast<const float4*>(s + w * Cp + Cp);
-  return make_float4(fmaxf(fmaxf(a0.x, a1.x), fmaxf(a2.x, a3.x)), fmaxf(fmaxf(a0.y, a1.y), fmaxf(a2.y, a3.y)),
-                     fmaxf(fmaxf(a0.z, a1.z), fmaxf(a2.z, a3.z)), fmaxf(fmaxf(a0.w, a1.w), fmaxf(a2.w, a3.w)));
-}
-__device__ __forceinline__ size_t node_plane(int mode, int H, int W) {
-  if (mode == FUSE_SAME) return (size_t)H * W;
-  if (mode == FUSE_UP2) return (size_t)(H >> 1) * (W >> 1);
-  if (mode == FUSE_UP4) return (size_t)(H >> 2) * (W >> 2);
-  return (size_t)H * W * 4;
-}
-
-__device__ __forceinline__ float node_act(float v, int act) {
-  // SiLU with the hardware exp2 / reciprocal (about 1e-7 relative error; the prologue is
-  // instruction-bound on the IEEE expf + division otherwise)
-  if (act == ACT_SILU) return __fdividef(v, 1.f + __expf(-v));
-  if (act == ACT_RELU) return fmaxf(v, 0.f);
-  return v;
 }
 
 // The resampling modes are template parameters: with them known at compile time the
