@@ -1,0 +1,30 @@
+"""bench.py prints ONE JSON line, last on stdout, with the fields the driver reads, and its
+frame 0 is the cfg3 fixture case (so the line carries its own parity figure)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_line():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1",
+                          "--time-batch", "2", "--streams", "2", "--no-cpu-baseline", "--no-uint8"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1
+    assert line["vs_baseline"] is None and line["dtype"] == "f32" and line["higher_is_better"] is True
+    assert line["config"]["frames_per_step"] == 4 and line["config"]["streams"] == 2
+    r = line["roofline"]
+    assert r["bound"] in ("mfma", "hbm") and r["peak"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert line["value"] > 0 and abs(line["value"] - 4 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"] + 1e-3
+    # frame 0 of the bench workload is the reference's own output for that input
+    assert line["parity_max_abs_mm_vs_reference_fixture"] < 1e-3
