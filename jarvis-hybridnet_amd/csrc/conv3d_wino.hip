@@ -79,19 +79,23 @@ __global__ __launch_bounds__(256, (kWTZ == 2 ? 2 : 1)) void conv3d_wino_kernel(c
   // ---- raw patch loads: 600 pixels x 2 channel quads = 1200 items, 5 per thread
   constexpr int ITER = (kWNP * 2 + 255) / 256;
   float4 pf[ITER];
-  auto patch_ok = [&](int idx, int c0, const float** src) -> bool {
+  // per-thread patch items: offsets and validity do not depend on the channel pass, so they are
+  // computed once (the commit / issue phases were dominated by this index arithmetic)
+  int poff[ITER];
+  unsigned okmask = 0;
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int idx = tid + it * 256;
     const int q = idx & 1, pix = idx >> 1;
     const int px = pix % kWPX, py = (pix / kWPX) % kWPY, pz = pix / (kWPX * kWPY);
     const int iz = z0 - 1 + pz, iy = y0 - 1 + py, ix = x0 - 1 + px;
-    *src = xin + ((size_t)(iz * a.H + iy) * a.W + ix) * a.cin_p + c0 + q * 4;
-    return idx < kWNP * 2 && iz >= 0 && iz < a.D && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-  };
-#pragma unroll
-  for (int it = 0; it < ITER; ++it) {
-    const float* src;
-    const bool ok = patch_ok(tid + it * 256, 0, &src);
-    pf[it] = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool ok = idx < kWNP * 2 && iz >= 0 && iz < a.D && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    poff[it] = ok ? ((iz * a.H + iy) * a.W + ix) * a.cin_p + q * 4 : 0;     // < 2^31 elements per image
+    okmask |= ok ? (1u << it) : 0u;
   }
+#pragma unroll
+  for (int it = 0; it < ITER; ++it)
+    pf[it] = (okmask >> it & 1) ? *reinterpret_cast<const float4*>(xin + poff[it]) : make_float4(0.f, 0.f, 0.f, 0.f);
 
   const float2* __restrict__ U2 = reinterpret_cast<const float2*>(a.u);
   const float2* V2 = reinterpret_cast<const float2*>(V);
@@ -114,10 +118,8 @@ __global__ __launch_bounds__(256, (kWTZ == 2 ? 2 : 1)) void conv3d_wino_kernel(c
     for (int it = 0; it < ITER; ++it) {
       const int idx = tid + it * 256;
       if (idx < kWNP * 2) {
-        const float* src;
-        const bool ok = patch_ok(idx, c0, &src);
         float4 v = pf[it];
-        if (ok && a.in_stats) {
+        if ((okmask >> it & 1) && a.in_stats) {
           const int c = c0 + (idx & 1) * 4;
           const float4 mu = *reinterpret_cast<const float4*>(nrm + c);
           const float4 rs = *reinterpret_cast<const float4*>(nrm + a.cin_p + c);
@@ -137,11 +139,9 @@ __global__ __launch_bounds__(256, (kWTZ == 2 ? 2 : 1)) void conv3d_wino_kernel(c
     // next pass's loads fly under this pass's transform and MFMAs
     if (c0 + 8 < a.cin_p) {
 #pragma unroll
-      for (int it = 0; it < ITER; ++it) {
-        const float* src;
-        const bool ok = patch_ok(tid + it * 256, c0 + 8, &src);
-        pf[it] = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+      for (int it = 0; it < ITER; ++it)
+        pf[it] = (okmask >> it & 1) ? *reinterpret_cast<const float4*>(xin + poff[it] + c0 + 8)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // 2. input transform: thread -> (z-slice pz, tile, channel quad q); 6 x 16 x 2 = 192 items
     if (tid < kWPZ * 32) {
