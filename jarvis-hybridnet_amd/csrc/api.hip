@@ -546,7 +546,7 @@ int jh_op_conv(int nd, int kind, int k, int stride, int pad, int cin, int cout,
                            cin * sizeof(float), n, hipMemcpyDeviceToDevice, s) != hipSuccess) { rc = 1; break; }
     }
     if ((rc = launch_to_channel_last(x_dev, x, s))) break;
-    if (wino) { if ((rc = launch_conv3d_wino(cw, x, y, stats, s, nullptr))) break; }
+    if (wino) { if ((rc = launch_conv3d_wino(cw, x, y, stats, s, nullptr, wino_variant_from_env()))) break; }
     else if ((rc = launch_conv(desc, cw, x, y, gate_p, stats, s))) break;
     if (norm_act >= 0 && (rc = launch_norm_apply(y, stats, 1e-5f, norm_act, nullptr, nullptr, y.p, nullptr, s))) break;
     if ((rc = launch_from_channel_last(y, y_dev, s))) break;

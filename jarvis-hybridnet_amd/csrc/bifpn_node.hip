@@ -419,7 +419,7 @@ static int launch_node_variant(const NodeArgs& a, size_t lds, hipStream_t s) {
 
 int launch_bifpn_node(const NodeArgs& args, hipStream_t s) {
   NodeArgs a = args;
-  if (const char* e = getenv("JH_NODE_ABL")) a.abl = atoi(e);   // timing experiments only
+  if (JH_ENV_KNOB("JH_NODE_ABL") >= 0) a.abl = JH_ENV_KNOB("JH_NODE_ABL");   // timing experiments only
   const size_t head = ((size_t)3 * a.Cp * 2 + (size_t)9 * a.Cp) * sizeof(float);
   const size_t at_bytes = (size_t)128 * (a.Cp + 4) * sizeof(float);
   const size_t red = (size_t)8 * kNodeNRG * 16 * 2 * sizeof(float);
@@ -428,17 +428,17 @@ int launch_bifpn_node(const NodeArgs& args, hipStream_t s) {
   // (3 workgroups per CU for the 56-channel pyramid of the small model)
   const size_t b_bytes = (size_t)(a.Cp / 8) * (a.cout_p16 / 16) * 128 * sizeof(float);
   a.blds = (b_bytes <= 16 * 1024) ? 1 : 0;        // 512 threads x 32 bytes
-  if (const char* e = getenv("JH_NODE_NOBLDS")) { if (atoi(e)) a.blds = 0; }
+  if (JH_ENV_KNOB("JH_NODE_NOBLDS") > 0) a.blds = 0;
   size_t lds = head + std::max(halo_px * a.Cp, at_bytes + (a.blds ? b_bytes : red));
   a.cf = a.Cp;
   a.alias = 1;
-  const char* na = getenv("JH_NODE_NOALIAS");
-  if (a.Cp > 64 || a.Cp < 32 || lds > 54 * 1024 || (na && atoi(na))) {
+  const bool na = JH_ENV_KNOB("JH_NODE_NOALIAS") > 0;
+  if (a.Cp > 64 || a.Cp < 32 || lds > 54 * 1024 || na) {
     // fallback: separate operand tile, halo chunked to the LDS budget
     a.alias = 0;
     a.blds = 0;
     size_t budget = 78 * 1024;
-    if (const char* e = getenv("JH_NODE_LDS_KB")) budget = (size_t)atoi(e) * 1024;
+    if (JH_ENV_KNOB("JH_NODE_LDS_KB") > 0) budget = (size_t)JH_ENV_KNOB("JH_NODE_LDS_KB") * 1024;
     const size_t fixed = head + at_bytes;
     if (fixed + halo_px * 12 > budget) budget = 156 * 1024;
     int cf = std::min(a.Cp, 64);          // the depthwise rounds handle <= 16 channel quads

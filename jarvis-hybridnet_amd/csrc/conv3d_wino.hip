@@ -364,8 +364,15 @@ int pack_wino_weights(int cin, int cout, const float* w, const float* b, ConvWei
   return 0;
 }
 
+// variant: 0 = 4 z-slices per workgroup (default), 1 = 2 z-slices, 2 = two-wave-set form
+int wino_variant_from_env() {
+  if (const char* e = getenv("JH_WINO_PP")) { if (atoi(e) != 0) return 2; }
+  if (const char* e = getenv("JH_WINO_TZ")) { if (atoi(e) == 2) return 1; }
+  return 0;
+}
+
 int launch_conv3d_wino(const ConvWeights& w, const Act& x, const Act& y, double* stats, hipStream_t s,
-                       const InNorm* in) {
+                       const InNorm* in, int variant) {
   JH_REQUIRE(x.Cp == w.cin_p && x.N == y.N && x.D == y.D && x.H == y.H && x.W == y.W, "wino shapes");
   WinoArgs a{};
   a.x = x.p; a.y = y.p; a.u = w.w; a.bias = w.bias; a.stats = stats;
@@ -374,16 +381,11 @@ int launch_conv3d_wino(const ConvWeights& w, const Act& x, const Act& y, double*
   const int nb = w.cout_p16 / 16;
   const int nr = (nb % 3 == 0) ? 3 : ((nb % 2 == 0) ? 2 : (nb == 1 ? 1 : 3));
   // measured (46->46 @ 32^3, 8 volumes): 4 z-slices 0.184 ms, 2 z-slices 0.188 ms -- the second
-  // resident workgroup does not pay for the doubled per-workgroup prologue / epilogue
-  int tz = 4;
-  if (const char* e = getenv("JH_WINO_TZ")) tz = atoi(e) == 2 ? 2 : 4;
-  // ping-pong form (conv3d_wino_pp.hip): two wave sets alternating MFMA / transform roles.
-  // Measured: 0.176 vs 0.182 ms per 8 frames alone, but no gain (1616 vs 1608 frames/s) once
-  // three time batches share the GPU -- it takes 137 KB of LDS and 8 waves per CU that the
-  // other streams' kernels could use -- so it is opt-in.
-  bool pp = false;
-  if (const char* e = getenv("JH_WINO_PP")) pp = atoi(e) != 0;
-  if (pp) return launch_conv3d_wino_pp(a, nr, s);
+  // resident workgroup does not pay for the doubled per-workgroup prologue / epilogue.  The
+  // two-wave-set form (conv3d_wino_pp.hip) is 0.176 ms alone but gains nothing once three time
+  // batches share the GPU (137 KB of LDS and 8 waves per CU), so both stay opt-in.
+  const int tz = variant == 1 ? 2 : 4;
+  if (variant == 2) return launch_conv3d_wino_pp(a, nr, s);
   const int blocks = ((x.D + tz - 1) / tz) * ((x.H + kWTY - 1) / kWTY) * ((x.W + kWTX - 1) / kWTX);
   dim3 grid(blocks, (nb + nr - 1) / nr, x.N);
   const size_t xbytes = (size_t)4 * 2 * tz * nr * 4 * 64 * sizeof(float);

@@ -153,7 +153,7 @@ int launch_conv(const ConvDesc& d, const ConvWeights& w, const Act& x, const Act
     // 16 x 16 tiles for high-resolution layers with few input channels
     int big = (a.Wout >= 64 && a.Hout >= 64 && w.cin_p <= 32 && d.ostride == 1 && d.stride == 1 &&
                (d.k == 1 || d.k == 3)) ? 1 : 0;   // (measured: stride-2 layers do not gain)
-    if (const char* e = getenv("JH_CONV2D_BIG")) big = big && atoi(e);
+    if (JH_ENV_KNOB("JH_CONV2D_BIG") == 0) big = 0;
     if (big) return conv_launch_2d_big(a, d.k, d.stride, nr, budget, s);
     if (d.k == 1 && d.stride == 1) return conv_launch_2d_k1(a, nr, small, budget, s);
     if (d.k == 2 && d.stride == 1) return conv_launch_2d_k2(a, nr, small, budget, s);
@@ -167,7 +167,7 @@ int launch_conv(const ConvDesc& d, const ConvWeights& w, const Act& x, const Act
     // 256-voxel tiles (4 row blocks per wave: half the weight traffic per MFMA, 2.5x
     // instead of 3.4x halo) once there are at least ~3 workgroups per CU of them
     if (!small && d.k == 3 && d.stride == 1 && tiles_big / 2 >= 768) small = 2;
-    if (const char* e = getenv("JH_CONV3D_TILE")) { if (!small || atoi(e) == 1) small = atoi(e); }
+    if (JH_ENV_KNOB("JH_CONV3D_TILE") >= 0) { const int v = JH_ENV_KNOB("JH_CONV3D_TILE"); if (!small || v == 1) small = v; }
     if (d.k == 1 && d.stride == 1) return conv_launch_3d_k1(a, nr, small, budget, s);
     if (d.k == 2 && d.stride == 2) return conv_launch_3d_k2s2(a, nr, small, budget, s);
     if (d.k == 3 && d.stride <= 2) return conv_launch_3d_k3(a, d.stride, nr, small, budget, s);

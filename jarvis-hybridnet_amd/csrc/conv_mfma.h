@@ -526,9 +526,9 @@ template <int ND, int K, int STRIDE, int TZ, int TY, int TX>
 int launch_conv_geom(const ConvArgs& a, int nr, size_t lds_budget, hipStream_t s) {
   using G = ConvGeom<ND, K, STRIDE, TZ, TY, TX>;
   ConvArgs b = a;
-  if (const char* e = getenv("JH_CONV_LDS_KB")) lds_budget = (size_t)atoi(e) * 1024;
+  if (JH_ENV_KNOB("JH_CONV_LDS_KB") > 0) lds_budget = (size_t)JH_ENV_KNOB("JH_CONV_LDS_KB") * 1024;
   int kc8 = pick_kc8(b.cin_p, &G::lds_bytes, lds_budget);
-  if (const char* e = getenv("JH_CONV_KC8")) kc8 = atoi(e);
+  if (JH_ENV_KNOB("JH_CONV_KC8") > 0) kc8 = JH_ENV_KNOB("JH_CONV_KC8");
   b.kc = kc8 * 8;
   const int tiles = ((b.Dout + TZ - 1) / TZ) * ((b.Hout + TY - 1) / TY) * ((b.Wout + TX - 1) / TX);
   const int nb = b.cout_p16 / 16;

@@ -8,6 +8,7 @@
 // and the layout the V2V input is produced in.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <cstdint>
 #include <cstdio>
 #include <string>
@@ -16,6 +17,10 @@
 namespace jh {
 
 constexpr int kWave = 64;
+
+// Experiment knobs (JH_* environment variables) are launch-path constants: each is read ONCE per
+// process (first use), not on every launch.  -1 = unset.
+#define JH_ENV_KNOB(name) ([]() -> int { static const int v = [] { const char* e = getenv(name); return e ? atoi(e) : -1; }(); return v; }())
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 inline int cpad(int c) { return round_up(c, 8); }
@@ -187,8 +192,9 @@ __device__ __forceinline__ BlockId xcd_block() {
 struct NodeArgs;
 int launch_bifpn_node(const NodeArgs& a, hipStream_t s);
 int pack_wino_weights(int cin, int cout, const float* w, const float* b, ConvWeights* out);
+int wino_variant_from_env();
 int launch_conv3d_wino(const ConvWeights& w, const Act& x, const Act& y, double* stats, hipStream_t s,
-                       const InNorm* in);
+                       const InNorm* in, int variant = 0);
 int launch_deconv_c1(const Act& x, const double* stats, float inv_cnt, int in_act, const float* w,
                      const Act& y, hipStream_t s);
 

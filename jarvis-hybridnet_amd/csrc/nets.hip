@@ -104,7 +104,8 @@ int Plan::add_conv(const ParamMap& pm, const ConvDesc& d, const std::string& wke
   if (!bkey.empty() && get(pm, bkey, d.cout, &b)) return 1;
   // 3x3x3 stride-1 convs (the V2V residual blocks) run as Winograd F(2x2,3x3) x direct z
   bool wino = d.nd == 3 && d.k == 3 && d.stride == 1 && d.ostride == 1 && !transposed && !gate;
-  if (const char* e = getenv("JH_WINO")) wino = wino && atoi(e) != 0;
+  if (const char* e = getenv("JH_WINO")) wino = wino && atoi(e) != 0;      // (plan build time)
+  const int wino_variant = wino ? wino_variant_from_env() : 0;
   ConvWeights cw;
   if (wino) {
     if (pack_wino_weights(d.cin, d.cout, w, b, &cw)) return 1;
@@ -128,10 +129,10 @@ int Plan::add_conv(const ParamMap& pm, const ConvDesc& d, const std::string& wke
   snprintf(nm, sizeof nm, "conv%dd_k%ds%d%s_%dx%d@%d", d.nd, d.ostride > 1 ? (d.nd == 2 ? 4 : 2) : d.k,
            d.ostride > 1 ? 2 : d.stride, d.ostride > 1 ? "T" : (wino ? "wino" : ""), d.cin, d.cout, y.W);
   push(nm, flops, bytes,
-       [this, d, cw, x, y, gate, want_stats, off, in_stats_off, in_inv, in_act, wino](hipStream_t s) {
+       [this, d, cw, x, y, gate, want_stats, off, in_stats_off, in_inv, in_act, wino, wino_variant](hipStream_t s) {
     InNorm in;
     if (in_stats_off >= 0) { in.stats = sc((size_t)in_stats_off); in.inv = in_inv; in.act = in_act; }
-    if (wino) return launch_conv3d_wino(cw, x, y, want_stats ? sc(off) : nullptr, s, &in);
+    if (wino) return launch_conv3d_wino(cw, x, y, want_stats ? sc(off) : nullptr, s, &in, wino_variant);
     return launch_conv(d, cw, x, y, gate, want_stats ? sc(off) : nullptr, s, &in);
   });
   return 0;
