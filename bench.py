@@ -65,6 +65,9 @@ def main():
     ap.add_argument("--no-uint8", action="store_true", help="skip the uint8-ingest side measurement")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph")
+    ap.add_argument("--sharded-streams", type=int, default=2,
+                    help="multi-GPU: camera-sharded pipelines in flight per rank (own plans and HIP stream each, "
+                         "one RCCL communicator: the collectives are issued in the same order on every rank)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="multi-GPU: do not overlap the heatmap exchange with the next step's 2D stage")
     ap.add_argument("--force-sharded", action="store_true",
@@ -95,8 +98,9 @@ def main():
 
     c = CONFIGS[args.config]
     if args.time_batch is None:
-        args.time_batch = 64 if sharded else 32
-    K = 1 if (sharded or args.graph) else max(1, args.streams)
+        args.time_batch = 32
+    KS = max(1, args.sharded_streams) if (sharded and not args.no_pipeline) else 1
+    K = KS if sharded else (1 if args.graph else max(1, args.streams))
     # Weak scaling: every rank always does the work of `--time-batch` whole frames
     # (T*C images of 2D work, T frames of 3D work).  Ranks form groups of `gs` GPUs
     # that shard the cameras of T*gs frames; world/gs groups run side by side.
@@ -141,13 +145,18 @@ def main():
         from jarvis_hybridnet_amd.distributed import ShardedPredictor, camera_range
         groups = [dist.new_group(list(range(g * gs, (g + 1) * gs))) for g in range(n_groups)]
         cam_lo, cam_n = camera_range(c["C"], grank, gs)
-        pred = NativePredictor(sd_c, sd_h, time_batch_3d=T // gs, cam_lo=cam_lo, cam_n=cam_n,
-                               **common)
-        pred.set_calibration(*[t.to(dev) for t in calib])
         fr = device_frames(cam_lo, cam_n)
-        sh = ShardedPredictor(pred, num_cameras=c["C"], num_joints=c["J"], time_batch=T,
-                              heat_shape=(pred.Hh, pred.Hh, pred.Jp), rank=grank, world=gs,
-                              device=dev, exchange=args.exchange, group=groups[gidx])
+        preds, shs = [], []
+        for _ in range(KS):
+            p_ = NativePredictor(sd_c, sd_h, time_batch_3d=T // gs, cam_lo=cam_lo, cam_n=cam_n, **common)
+            p_.set_calibration(*[t.to(dev) for t in calib])
+            preds.append(p_)
+            shs.append(ShardedPredictor(p_, num_cameras=c["C"], num_joints=c["J"], time_batch=T,
+                                        heat_shape=(p_.Hh, p_.Hh, p_.Jp), rank=grank, world=gs,
+                                        device=dev, exchange=args.exchange, group=groups[gidx]))
+        pred, sh = preds[0], shs[0]
+        sh_streams = [torch.cuda.Stream() for _ in range(KS)]
+        torch.cuda.synchronize()
 
         def step():
             return sh.step(fr)
@@ -169,14 +178,25 @@ def main():
         run()
     if sharded and not args.no_pipeline:
         # consecutive time batches pipelined: the heatmap exchange of step i runs under the
-        # CenterDetect stage of step i+1; K submits + the final flush = exactly K whole steps
-        run = lambda: sh.submit(fr)
+        # CenterDetect stage of step i+1; K submits + the final flush = exactly K whole steps.
+        # KS such pipelines run on KS HIP streams (every rank issues their collectives in the
+        # same order on the one communicator of its group).
+        for k in range(1, KS):                     # warm the other pipelines too
+            with torch.cuda.stream(sh_streams[k]):
+                shs[k].step(fr)
+
+        def run():
+            for k in range(KS):
+                with torch.cuda.stream(sh_streams[k]):
+                    shs[k].submit(fr)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run()
     if sharded and not args.no_pipeline:
-        sh.flush()
+        for k in range(KS):
+            with torch.cuda.stream(sh_streams[k]):
+                shs[k].flush()
     barrier()
     dt = time.perf_counter() - t0
     if sharded:
@@ -203,8 +223,9 @@ def main():
                    "parallelism": ("single GPU, %d time batches in flight on %d HIP streams" % (K, K))
                    if not sharded else
                    "%d group(s) x %d GPUs: camera-sharded 2D (%d cams/GPU) + RCCL %s of "
-                   "heatmaps%s + frame-sharded 3D" % (n_groups, gs, c["C"] // gs, args.exchange,
-                                                       "" if args.no_pipeline else " (overlapped with the next step's CenterDetect)"),
+                   "heatmaps%s + frame-sharded 3D; %d such pipeline(s) per rank" % (
+                       n_groups, gs, c["C"] // gs, args.exchange,
+                       "" if args.no_pipeline else " (overlapped with the next step's CenterDetect)", KS),
                    "launches_per_step": int(pred.launches) * K, "launches_per_time_batch": int(pred.launches),
                    "hipgraph": bool(args.graph)},
     }
@@ -354,7 +375,7 @@ def main():
         # every rank runs the whole path on its own `--time-batch` frames, no data-path
         # collective (what a throughput-only deployment would do)
         try:
-            del sh, pred, fr
+            del sh, pred, fr, shs, preds
             torch.cuda.empty_cache()
             from jarvis_hybridnet_amd._predictor import MultiStreamPredictor
             Tb, Kr = 32, max(1, args.streams)
