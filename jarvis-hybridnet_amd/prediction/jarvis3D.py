@@ -37,22 +37,36 @@ class JarvisPredictor3D(nn.Module):
         self.center_detect_img_size = int(cfg.CENTERDETECT.IMAGE_SIZE)
         self._native = {}
 
+    def _make_native(self, img_h, img_w, time_batch, cam_lo, cam_n):
+        c = self.cfg
+        return NativePredictor(
+            flat_state(self.centerDetect), flat_state(self.hybridNet),
+            num_cameras=self.num_cameras, num_joints=c.KEYPOINTDETECT.NUM_JOINTS,
+            center_size=self.center_detect_img_size, bbox=self.bounding_box_size,
+            roi_cube_size=c.HYBRIDNET.ROI_CUBE_SIZE, grid_spacing=c.HYBRIDNET.GRID_SPACING,
+            img_h=img_h, img_w=img_w, mean=list(c.DATASET.MEAN), std=list(c.DATASET.STD),
+            center_model=c.CENTERDETECT.MODEL_SIZE, kp_model=c.KEYPOINTDETECT.MODEL_SIZE,
+            time_batch=time_batch, cam_lo=cam_lo, cam_n=cam_n)
+
     def native(self, img_h, img_w, time_batch=1, cam_lo=0, cam_n=None):
         """The native predictor for a frame size (built on first use)."""
         key = (img_h, img_w, time_batch, cam_lo, cam_n)
         pr = self._native.get(key)
         if pr is None:
-            c = self.cfg
-            pr = NativePredictor(
-                flat_state(self.centerDetect), flat_state(self.hybridNet),
-                num_cameras=self.num_cameras, num_joints=c.KEYPOINTDETECT.NUM_JOINTS,
-                center_size=self.center_detect_img_size, bbox=self.bounding_box_size,
-                roi_cube_size=c.HYBRIDNET.ROI_CUBE_SIZE, grid_spacing=c.HYBRIDNET.GRID_SPACING,
-                img_h=img_h, img_w=img_w, mean=list(c.DATASET.MEAN), std=list(c.DATASET.STD),
-                center_model=c.CENTERDETECT.MODEL_SIZE, kp_model=c.KEYPOINTDETECT.MODEL_SIZE,
-                time_batch=time_batch, cam_lo=cam_lo, cam_n=cam_n)
-            self._native[key] = pr
+            pr = self._native[key] = self._make_native(img_h, img_w, time_batch, cam_lo, cam_n)
         return pr
+
+    def native_streams(self, img_h, img_w, time_batch, streams):
+        """`streams` native predictors of that shape (own launch plans and buffers each) behind a
+        MultiStreamPredictor: independent time batches in flight on `streams` HIP streams (the
+        throughput form, see _predictor.MultiStreamPredictor)."""
+        from .._predictor import MultiStreamPredictor
+        key = ("streams", img_h, img_w, time_batch, streams)
+        msp = self._native.get(key)
+        if msp is None:
+            msp = self._native[key] = MultiStreamPredictor(
+                lambda: self._make_native(img_h, img_w, time_batch, 0, None), streams=streams)
+        return msp
 
     def forward(self, imgs, cameraMatrices, intrinsicMatrices, distortionCoefficients):
         """imgs (C,3,H,W) RGB in [0,1] -> (points3D (1,J,3), confidences (1,J)) or (None, None)."""

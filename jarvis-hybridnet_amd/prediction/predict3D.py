@@ -41,7 +41,7 @@ def frame_row(points3D, confidences, num_joints):
 
 
 def predict3D_frames(predictor, frame_sets, cameraMatrices, intrinsicMatrices,
-                     distortionCoefficients, cfg, output_dir, params=None, time_batch=1):
+                     distortionCoefficients, cfg, output_dir, params=None, time_batch=1, streams=1):
     """Run `predictor` over an iterable of multi-view frame sets -- (C,H,W,3) uint8 BGR
     arrays / tensors exactly as cv2 delivers them, or (C,3,H,W) fp32 RGB -- and write
     data3D.csv (+ info.yaml when `params` is given).  Returns the number of frames.
@@ -49,7 +49,9 @@ def predict3D_frames(predictor, frame_sets, cameraMatrices, intrinsicMatrices,
     time_batch > 1 groups that many consecutive frame sets into one launch sequence
     (`forward_batch`, the throughput form the bench measures); rows are written in frame
     order and are the same as with time_batch = 1.  A short last group is padded with
-    its last frame set and the padding rows are dropped."""
+    its last frame set and the padding rows are dropped.  streams > 1 (with time_batch > 1)
+    keeps that many groups in flight on as many HIP streams; rows still come out in frame
+    order and are identical."""
     os.makedirs(output_dir, exist_ok=True)
     if params is not None:
         params.output_dir = output_dir
@@ -63,10 +65,30 @@ def predict3D_frames(predictor, frame_sets, cameraMatrices, intrinsicMatrices,
         if len(names) == J:
             create_header(writer, cfg)
 
+        inflight = []                               # (outputs, event, real) of submitted groups
+
+        def drain(keep):
+            while len(inflight) > keep:
+                (pts, conf, valid), ev, real = inflight.pop(0)
+                ev.synchronize()
+                pts, conf, valid = pts.cpu(), conf.cpu(), valid.cpu()
+                for t in range(real):
+                    ok = int(valid[t]) != 0
+                    writer.writerow(frame_row(pts[t] if ok else None, conf[t] if ok else None, J))
+
         def flush(group):
             real = len(group)
             group = group + [group[-1]] * (time_batch - real)
-            pts, conf, valid = predictor.forward_batch(torch.stack(group).cuda(), *calib)
+            x = torch.stack(group).cuda()
+            if streams > 1:
+                h, w = (x.shape[2], x.shape[3]) if x.dtype == torch.uint8 else (x.shape[3], x.shape[4])
+                msp = predictor.native_streams(h, w, time_batch, streams)
+                msp.set_calibration(*calib)
+                drain(streams - 1)                  # the stream about to be reused must be idle
+                res = msp.forward(x)
+                inflight.append((res, msp.last_event, real))
+                return real
+            pts, conf, valid = predictor.forward_batch(x, *calib)
             pts, conf, valid = pts.cpu(), conf.cpu(), valid.cpu()
             for t in range(real):
                 ok = int(valid[t]) != 0
@@ -79,6 +101,7 @@ def predict3D_frames(predictor, frame_sets, cameraMatrices, intrinsicMatrices,
             if time_batch > 1:
                 if group and (x.dtype != group[0].dtype or x.shape != group[0].shape):
                     n += flush(group)
+                    drain(0)
                     group = []
                 group.append(x)
                 if len(group) == time_batch:
@@ -93,4 +116,5 @@ def predict3D_frames(predictor, frame_sets, cameraMatrices, intrinsicMatrices,
             n += 1
         if group:
             n += flush(group)
+        drain(0)
     return n

@@ -220,6 +220,10 @@ def test_predict3d_frames_writes_csv(tmp_path, golden):
     n = predict3D_frames(pred, [u8, u8, u8], *dev, cfg, str(tmp_path / "tb"), time_batch=2)
     rows2 = list(csv.reader(open(tmp_path / "tb" / "data3D.csv")))
     assert n == 3 and len(rows2) == 5 and rows2[2] == rows2[3] == rows2[4] == rows[3]
+    # ... and with three such groups in flight on three HIP streams (7 frame sets: 4 groups)
+    n = predict3D_frames(pred, [u8] * 7, *dev, cfg, str(tmp_path / "ms"), time_batch=2, streams=3)
+    rows3 = list(csv.reader(open(tmp_path / "ms" / "data3D.csv")))
+    assert n == 7 and len(rows3) == 9 and all(r == rows[3] for r in rows3[2:])
 
 
 def test_error_paths_are_loud():
