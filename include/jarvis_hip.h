@@ -4,8 +4,13 @@
  * This is the drop-in boundary: plain C, raw device pointers, explicit shapes,
  * an explicit hipStream_t (passed as void*), int status (0 = OK; the message of
  * the last failure on the calling thread is returned by jh_last_error()).
- * No function synchronises the device or allocates caller-visible memory during
- * a forward call, so a whole forward may be captured into a hipGraph.
+ * No forward entry point synchronises the device or allocates memory: networks and
+ * predictors own their intermediates (allocated by *_create), the stand-alone
+ * operators (jh_reproject_forward, jh_softargmax, jh_reconstruct_point) take a
+ * caller-provided device workspace sized by the matching jh_*_workspace_bytes().
+ * A whole forward may therefore be captured into a hipGraph
+ * (tests/test_hip_stages.py::test_submodule_path_graph_capture).  The only
+ * exceptions are the jh_op_* unit-test helpers at the end of this file, which say so.
  *
  * The library occupies the seam the reference itself uses for acceleration:
  * JarvisPredictor3D replaces three sub-networks by compiled modules after
@@ -27,7 +32,7 @@
 extern "C" {
 #endif
 
-#define JH_ABI_VERSION 1
+#define JH_ABI_VERSION 2
 
 const char* jh_last_error(void);
 int jh_abi_version(void);
@@ -42,12 +47,16 @@ void jh_params_destroy(jh_params* p);
 
 /* ---- EfficientTrackBackbone.forward  (jarvis/efficienttrack/model.py:114-130)
  * model_size: 0 small, 1 medium, 2 large.  Built for a fixed (N,3,H,W) input.
- * forward: x (N,3,H,W) NCHW dev -> res2 (N,J,H/2,W/2) NCHW dev.  The res1
- * branch (final_conv1) is dead on the inference path and is not computed. */
+ * forward: x (N,3,H,W) NCHW dev -> res1 (N,J,H/4,W/4), res2 (N,J,H/2,W/2) NCHW dev:
+ * the (res1, res2) tuple of model.py:126-130, i.e. the tensor contract of the
+ * reference's trt_mode seam (jarvis3D.py:64-69).  res1 (final_conv1, model.py:128) is
+ * never read on the inference path (hybridnet/model.py:57-58, jarvis3D.py:147): it is
+ * computed only by networks created with want_res1 != 0, and res1_dev may be NULL. */
 typedef struct jh_efftrack jh_efftrack;
 int jh_efftrack_create(const jh_params* p, const char* prefix, int model_size, int joints, int n,
-                       int h, int w, jh_efftrack** out);
-int jh_efftrack_forward(jh_efftrack* net, const float* x_dev, float* res2_dev, void* stream);
+                       int h, int w, int want_res1, jh_efftrack** out);
+int jh_efftrack_forward(jh_efftrack* net, const float* x_dev, float* res1_dev, float* res2_dev,
+                        void* stream);
 int64_t jh_efftrack_launches(const jh_efftrack* net);
 void jh_efftrack_destroy(jh_efftrack* net);
 
@@ -62,28 +71,37 @@ void jh_v2v_destroy(jh_v2v* net);
  * heatmaps_padded (1,C,J,hs,hs) NCHW dev, center3d (3) int32 dev, center_hm
  * (C,2) int32 dev, calibration dev -> vol (1,J,G,G,G) NCDHW dev (NOT divided by
  * 255, like the reference layer).  idx_dev (C,G,G,G) int32 optional (may be
- * NULL): the reference's integer gather index (reprojectPoints, :40-85). */
+ * NULL): the reference's integer gather index (reprojectPoints, :40-85).
+ * workspace_dev: >= jh_reproject_workspace_bytes(cams, joints, hs, grid_size) bytes of
+ * device memory (256-byte aligned), owned by the caller, contents irrelevant. */
+int64_t jh_reproject_workspace_bytes(int cams, int joints, int hs, int grid_size);
 int jh_reproject_forward(const float* heatmaps_padded_dev, int cams, int joints, int hs,
                          const int32_t* center3d_dev, const int32_t* center_hm_dev,
                          const float* cam_dev, const float* intr_dev, const float* dist_dev,
                          int grid_size, float grid_spacing, float* vol_dev, int32_t* idx_dev,
-                         void* stream);
+                         void* workspace_dev, int64_t workspace_bytes, void* stream);
 
 /* ---- soft-argmax tail of HybridNetBackbone.forward (hybridnet/model.py:73-88)
  * v2v_out (T,J,Gh,Gh,Gh) NCDHW dev, center3d (T,3) int32 dev -> points (T,J,3),
- * conf (T,J), heatmap_final (T,J,Gh,Gh,Gh) optional (NULL to skip). */
+ * conf (T,J), heatmap_final (T,J,Gh,Gh,Gh) optional (NULL to skip).
+ * workspace_dev: >= jh_softargmax_workspace_bytes(t, joints, gh) bytes, as above. */
+int64_t jh_softargmax_workspace_bytes(int t, int joints, int gh);
 int jh_softargmax(const float* v2v_out_dev, int t, int joints, int gh, float grid_spacing,
                   float roi_cube_size, const int32_t* center3d_dev, float* heatmap_final_dev,
-                  float* points_dev, float* conf_dev, void* stream);
+                  float* points_dev, float* conf_dev, void* workspace_dev, int64_t workspace_bytes,
+                  void* stream);
 
 /* ---- ReprojectionTool  (jarvis/utils/reprojection.py:49-90)
  * reproject: points (P,3) dev -> uv (C,P,2) dev.
- * reconstruct: points2d (2,C) dev (pixels), maxvals (C) dev -> point3d (3) dev. */
+ * reconstruct: points2d (2,C) dev (pixels), maxvals (C) dev -> point3d (3) dev;
+ * workspace_dev: >= jh_reconstruct_workspace_bytes(cams) bytes, as above. */
 int jh_reproject_point(const float* points_dev, int npoints, int cams, const float* cam_dev,
                        const float* intr_dev, const float* dist_dev, float* uv_dev, void* stream);
+int64_t jh_reconstruct_workspace_bytes(int cams);
 int jh_reconstruct_point(const float* points2d_dev, const float* maxvals_dev, int cams,
                          const float* cam_dev, const float* intr_dev, const float* dist_dev,
-                         float* point3d_dev, void* stream);
+                         float* point3d_dev, void* workspace_dev, int64_t workspace_bytes,
+                         void* stream);
 
 /* ---- JarvisPredictor3D  (jarvis/prediction/jarvis3D.py:20-46,129-190) and
  * HybridNetBackbone.forward (jarvis/hybridnet/model.py:53-90).
@@ -187,7 +205,9 @@ int jh_profile_begin(void);
 int jh_profile_end(int* n_records);
 int jh_profile_get(int i, char* name, int name_cap, double* ms, double* flops, double* bytes);
 
-/* ---- single-operator entry points (building blocks; used by the unit tests)
+/* ---- single-operator entry points (unit-test helpers, NOT part of the forward path:
+ * they repack host weights, allocate scratch with hipMalloc and end in a stream
+ * synchronisation, so they are neither asynchronous nor graph-capturable)
  * conv: x (N,Cin,[D,]H,W) -> y; weights/bias are HOST pointers in torch layout
  * ((Cout,Cin,k..) or, transposed, (Cin,Cout,k..)); kind 0 = conv (k, stride,
  * pad), 1 = ConvTranspose2d k4 s2 p1, 2 = ConvTranspose3d k2 s2.  When

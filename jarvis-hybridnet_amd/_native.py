@@ -28,29 +28,51 @@ class PredictorConfig(ctypes.Structure):
                 ("cam_n", ctypes.c_int32), ("mean", c_float * 3), ("std", c_float * 3)]
 
 
+ABI_VERSION = 2                      # JH_ABI_VERSION of include/jarvis_hip.h
+# sizeof(jh_predictor_config): statically asserted on the C side (tests/abi_smoke.c) and here
+assert ctypes.sizeof(PredictorConfig) == 80
+
+_WORKSPACES = {}
+
+
+def workspace(nbytes, device):
+    """A cached device byte buffer of at least `nbytes` (the caller-provided workspace of the
+    stand-alone operators).  One buffer per device: those operators run on the current
+    stream, in order."""
+    key = str(device)
+    buf = _WORKSPACES.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = _WORKSPACES[key] = torch.empty((max(int(nbytes), 256),), dtype=torch.uint8,
+                                             device=device)
+    return buf
+
+
 _SIGS = {
     "jh_last_error": (c_char_p, []),
     "jh_abi_version": (c_int, []),
     "jh_params_create": (c_int, [ctypes.POINTER(c_void_p)]),
     "jh_params_set": (c_int, [c_void_p, c_char_p, c_void_p, c_int64]),
     "jh_params_destroy": (None, [c_void_p]),
-    "jh_efftrack_create": (c_int, [c_void_p, c_char_p, c_int, c_int, c_int, c_int, c_int,
+    "jh_efftrack_create": (c_int, [c_void_p, c_char_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                    ctypes.POINTER(c_void_p)]),
-    "jh_efftrack_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "jh_efftrack_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "jh_efftrack_launches": (c_int64, [c_void_p]),
     "jh_efftrack_destroy": (None, [c_void_p]),
     "jh_v2v_create": (c_int, [c_void_p, c_char_p, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
     "jh_v2v_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "jh_v2v_destroy": (None, [c_void_p]),
+    "jh_reproject_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
     "jh_reproject_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p,
-                                     c_void_p]),
+                                     c_void_p, c_int64, c_void_p]),
+    "jh_softargmax_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "jh_softargmax": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p,
-                              c_void_p, c_void_p, c_void_p]),
+                              c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "jh_reproject_point": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p]),
+    "jh_reconstruct_workspace_bytes": (c_int64, [c_int]),
     "jh_reconstruct_point": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
-                                     c_void_p, c_void_p]),
+                                     c_void_p, c_void_p, c_int64, c_void_p]),
     "jh_predictor_create": (c_int, [c_void_p, c_void_p, ctypes.POINTER(PredictorConfig),
                                     ctypes.POINTER(c_void_p)]),
     "jh_predictor_destroy": (None, [c_void_p]),
@@ -101,7 +123,7 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(handle, name)          # AttributeError if the .so lacks a symbol
             fn.restype, fn.argtypes = res, args
-        if handle.jh_abi_version() != 1:
+        if handle.jh_abi_version() != ABI_VERSION:
             raise RuntimeError("libjarvis_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -25,21 +25,31 @@ def flat_state(module, prefix=""):
 
 class NativeModule(nn.Module):
     """nn.Module whose forward runs in libjarvis_hip; native plans are rebuilt
-    whenever parameters are (re)loaded or the input shape changes."""
+    whenever parameters are (re)loaded or the input shape changes.
+
+    `weights_version` counts loads into this module -- directly or through any parent's
+    load_state_dict (the post hook fires for every module of the recursion) -- so owners of
+    plans built from several modules (JarvisPredictor3D, HybridNetBackbone) can tell that
+    their packed copies are stale."""
 
     def __init__(self):
         super().__init__()
         self._plans = {}
+        self.weights_version = 0
+        self.register_load_state_dict_post_hook(NativeModule._loaded)
+
+    @staticmethod
+    def _loaded(module, incompatible_keys):
+        module.weights_version += 1
+        module._invalidate()
 
     def _invalidate(self):
         for plan in self._plans.values():
             plan.close()
         self._plans = {}
 
-    def load_state_dict(self, state_dict, strict=True, **kw):
-        res = super().load_state_dict(state_dict, strict=strict, **kw)
-        self._invalidate()
-        return res
 
-    def _apply(self, fn, *a, **k):          # .cuda() / .to(): parameters move, plans stay valid
-        return super()._apply(fn, *a, **k)
+def weights_fingerprint(*modules):
+    """(weights_version of every NativeModule below the given modules)."""
+    return tuple(m.weights_version for root in modules for m in root.modules()
+                 if isinstance(m, NativeModule))

@@ -48,6 +48,7 @@ class NativePredictor:
     def forward(self, frames, out=None):
         """frames (T,C,3,H,W) fp32 RGB, or (T,C,H,W,3) uint8 BGR as decoded
         -> points (T,J,3), conf (T,J), valid (T) int32."""
+        self._check_frames(frames, self.Cloc)
         dev = frames.device
         if out is None:
             out = (torch.empty((self.T, self.J, 3), device=dev),
@@ -59,13 +60,30 @@ class NativePredictor:
                    N.stream()))
         return out
 
+    def _check_frames(self, frames, cams):
+        """Raw pointers cross the C ABI: refuse anything whose bytes would be misread."""
+        H, W = self.cfg.img_h, self.cfg.img_w
+        if not (torch.is_tensor(frames) and frames.is_cuda and frames.is_contiguous()):
+            raise RuntimeError("frames must be a contiguous CUDA (HIP) tensor")
+        if frames.dtype == torch.uint8:
+            want = (self.T, cams, H, W, 3)
+        elif frames.dtype == torch.float32:
+            want = (self.T, cams, 3, H, W)
+        else:
+            raise RuntimeError("frames must be float32 RGB (T,C,3,H,W) or uint8 BGR (T,C,H,W,3); "
+                               "got dtype %s" % frames.dtype)
+        if tuple(frames.shape) != want:
+            raise RuntimeError("frames shape %s, expected %s" % (tuple(frames.shape), want))
+
     # ---- camera-sharded stages -------------------------------------------
     def stage_center(self, frames, det):
+        self._check_frames(frames, self.Cloc)
         fn = N.lib().jh_predictor_stage_center_u8 if frames.dtype == torch.uint8 else \
             N.lib().jh_predictor_stage_center
         N.check(fn(self.handle, N.ptr(frames), N.ptr(det), N.stream()))
 
     def stage_keypoints(self, frames, det_all, heat):
+        self._check_frames(frames, self.Cloc)
         fn = N.lib().jh_predictor_stage_keypoints_u8 if frames.dtype == torch.uint8 else \
             N.lib().jh_predictor_stage_keypoints
         N.check(fn(self.handle, N.ptr(frames), N.ptr(det_all), N.ptr(heat), N.stream()))
@@ -117,16 +135,37 @@ class MultiStreamPredictor:
         self.streams = [torch.cuda.Stream() for _ in range(streams)]
         self.events = [None] * streams
         self._next = 0
+        self._calib = None
 
     def set_calibration(self, *calib):
-        for p in self.preds:
-            p.set_calibration(*calib)
+        """Calibration of every predictor, written on that predictor's OWN stream (so the copy
+        is ordered against the forwards in flight there).  Setting the same tensors again is a
+        no-op: drivers may call this once per group of frames."""
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in calib)
+        if key == self._calib:
+            return
+        cur = torch.cuda.current_stream()
+        for p, s in zip(self.preds, self.streams):
+            s.wait_stream(cur)
+            with torch.cuda.stream(s):
+                p.set_calibration(*calib)
+            for t in calib:
+                if t.is_cuda:
+                    t.record_stream(s)
+        self._calib = key
 
     def forward(self, frames, out=None):
         i = self._next
         self._next = (i + 1) % len(self.preds)
         s = self.streams[i]
         s.wait_stream(torch.cuda.current_stream())       # `frames` may still be in the making
+        # The kernels see raw pointers only, so the caching allocator must be told that the
+        # side stream uses these blocks: without record_stream a caller that drops `frames`
+        # right after this call could get the same memory back for its next batch while the
+        # forward in flight here still reads it (it reads the frames twice: resize, then crops).
+        frames.record_stream(s)
+        for t in (out or ()):
+            t.record_stream(s)
         with torch.cuda.stream(s):
             res = self.preds[i].forward(frames, out)
             ev = torch.cuda.Event()

@@ -33,6 +33,48 @@ struct Scratch {
   }
 };
 
+// Caller-provided workspace, carved into 256-byte aligned pieces.  With base == nullptr it
+// only measures (jh_*_workspace_bytes).
+struct Carver {
+  char* base;
+  size_t cap, off = 0;
+  Carver(void* b, size_t c) : base(static_cast<char*>(b)), cap(c) {}
+  template <typename T> T* take(size_t count) {
+    const size_t at = off;
+    off += (count * sizeof(T) + 255) / 256 * 256;
+    return base ? reinterpret_cast<T*>(base + at) : nullptr;
+  }
+  void act(int N, int D, int H, int W, int C, Act* a) {
+    a->N = N; a->D = D; a->H = H; a->W = W; a->C = C; a->Cp = cpad(C);
+    a->p = take<float>(a->elems());
+  }
+  bool fits() const { return off <= cap; }
+};
+
+struct ReproWs { Act heat, vol; float2* coarse; };
+static size_t carve_reproject(Carver& c, int cams, int joints, int hs, int g, ReproWs* w) {
+  const int gh = g / 2;
+  c.act(cams, 1, hs, hs, joints, &w->heat);
+  c.act(1, g, g, g, joints, &w->vol);
+  w->coarse = c.take<float2>((size_t)cams * gh * gh * gh);
+  return c.off;
+}
+struct SoftWs { Act x; double* partial; int* pmax; };
+static size_t carve_softargmax(Carver& c, int t, int joints, int gh, SoftWs* w) {
+  c.act(t, gh, gh, gh, joints, &w->x);
+  w->partial = c.take<double>((size_t)t * w->x.Cp * 4);
+  w->pmax = c.take<int>((size_t)t * w->x.Cp);
+  return c.off;
+}
+struct ReconWs { float* det; int *c3i, *chm, *valid; };
+static size_t carve_reconstruct(Carver& c, int cams, ReconWs* w) {
+  w->det = c.take<float>((size_t)cams * 3);
+  w->c3i = c.take<int>(3);
+  w->chm = c.take<int>((size_t)cams * 2);
+  w->valid = c.take<int>(1);
+  return c.off;
+}
+
 // (T,C) channel-last heatmaps [N][Hh][Hh][Jp] -> padded NCHW (N,J,hs,hs)
 __global__ void export_padded_kernel(const float* __restrict__ heat, float* __restrict__ out, int N,
                                      int J, int Jp, int Hh) {
@@ -80,17 +122,21 @@ void jh_params_destroy(jh_params* p) { delete p; }
 
 // ---------------------------------------------------------------- EfficientTrack
 int jh_efftrack_create(const jh_params* p, const char* prefix, int model_size, int joints, int n,
-                       int h, int w, jh_efftrack** out) {
+                       int h, int w, int want_res1, jh_efftrack** out) {
   JH_REQUIRE(p && out, "bad argument");
   std::unique_ptr<jh_efftrack> net(new jh_efftrack());
-  if (net->plan.build(p->map, prefix ? prefix : "", model_size, joints, n, h, w)) return 1;
+  if (net->plan.build(p->map, prefix ? prefix : "", model_size, joints, n, h, w, want_res1 != 0)) return 1;
   *out = net.release();
   return 0;
 }
-int jh_efftrack_forward(jh_efftrack* net, const float* x_dev, float* res2_dev, void* stream) {
+int jh_efftrack_forward(jh_efftrack* net, const float* x_dev, float* res1_dev, float* res2_dev,
+                        void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
+  JH_REQUIRE(net && x_dev && res2_dev, "bad argument");
+  JH_REQUIRE(!res1_dev || net->plan.res1.p, "res1 requested from a network created with want_res1 = 0");
   if (launch_to_channel_last(x_dev, net->plan.input, s)) return 1;
   if (net->plan.run(s)) return 1;
+  if (res1_dev && launch_from_channel_last(net->plan.res1, res1_dev, s)) return 1;
   return launch_from_channel_last(net->plan.heat, res2_dev, s);
 }
 int64_t jh_efftrack_launches(const jh_efftrack* net) { return (int64_t)net->plan.launches(); }
@@ -113,43 +159,50 @@ int jh_v2v_forward(jh_v2v* net, const float* x_dev, float* y_dev, void* stream) 
 void jh_v2v_destroy(jh_v2v* net) { delete net; }
 
 // ------------------------------------------------------------------ reprojection
+int64_t jh_reproject_workspace_bytes(int cams, int joints, int hs, int grid_size) {
+  Carver c(nullptr, 0);
+  ReproWs w;
+  return (int64_t)carve_reproject(c, cams, joints, hs, grid_size, &w);
+}
+
 int jh_reproject_forward(const float* heatmaps_padded_dev, int cams, int joints, int hs,
                          const int32_t* center3d_dev, const int32_t* center_hm_dev,
                          const float* cam_dev, const float* intr_dev, const float* dist_dev,
                          int grid_size, float grid_spacing, float* vol_dev, int32_t* idx_dev,
-                         void* stream) {
+                         void* workspace_dev, int64_t workspace_bytes, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
-  Scratch sc;
-  Act heat, vol;
-  if (sc.act(cams, 1, hs, hs, joints, &heat)) return 1;
-  if (sc.act(1, grid_size, grid_size, grid_size, joints, &vol)) return 1;
-  float2* coarse;
-  const int gh = grid_size / 2;
-  if (sc.get(reinterpret_cast<void**>(&coarse), (size_t)cams * gh * gh * gh * sizeof(float2))) return 1;
-  if (launch_to_channel_last(heatmaps_padded_dev, heat, s)) return 1;
-  if (launch_reproject(cam_dev, intr_dev, dist_dev, center3d_dev, center_hm_dev, heat.p, coarse,
-                       vol.p, idx_dev, 1, cams, grid_size, grid_spacing, hs, heat.Cp, /*heat_pad=*/1,
-                       /*div255=*/0, s)) return 1;
-  if (launch_from_channel_last(vol, vol_dev, s)) return 1;
-  JH_CHECK_HIP(hipStreamSynchronize(s));
-  return 0;
+  JH_REQUIRE(workspace_dev && workspace_bytes >= 0, "workspace (see jh_reproject_workspace_bytes)");
+  JH_REQUIRE(grid_size > 0 && grid_size % 2 == 0, "grid size must be even");
+  Carver c(workspace_dev, (size_t)workspace_bytes);
+  ReproWs w;
+  carve_reproject(c, cams, joints, hs, grid_size, &w);
+  JH_REQUIRE(c.fits(), "workspace smaller than jh_reproject_workspace_bytes()");
+  if (launch_to_channel_last(heatmaps_padded_dev, w.heat, s)) return 1;
+  if (launch_reproject(cam_dev, intr_dev, dist_dev, center3d_dev, center_hm_dev, w.heat.p, w.coarse,
+                       w.vol.p, idx_dev, 1, cams, grid_size, grid_spacing, hs, w.heat.Cp,
+                       /*heat_pad=*/1, /*div255=*/0, s)) return 1;
+  return launch_from_channel_last(w.vol, vol_dev, s);
+}
+
+int64_t jh_softargmax_workspace_bytes(int t, int joints, int gh) {
+  Carver c(nullptr, 0);
+  SoftWs w;
+  return (int64_t)carve_softargmax(c, t, joints, gh, &w);
 }
 
 int jh_softargmax(const float* v2v_out_dev, int t, int joints, int gh, float grid_spacing,
                   float roi_cube_size, const int32_t* center3d_dev, float* heatmap_final_dev,
-                  float* points_dev, float* conf_dev, void* stream) {
+                  float* points_dev, float* conf_dev, void* workspace_dev, int64_t workspace_bytes,
+                  void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
-  Scratch sc;
-  Act x;
-  if (sc.act(t, gh, gh, gh, joints, &x)) return 1;
-  double* partial; int* pmax;
-  if (sc.get(reinterpret_cast<void**>(&partial), (size_t)t * x.Cp * 4 * sizeof(double))) return 1;
-  if (sc.get(reinterpret_cast<void**>(&pmax), (size_t)t * x.Cp * sizeof(int))) return 1;
-  if (launch_to_channel_last(v2v_out_dev, x, s)) return 1;
-  if (launch_softargmax(x.p, center3d_dev, partial, pmax, points_dev, conf_dev, heatmap_final_dev, t,
-                        joints, x.Cp, gh, grid_spacing, roi_cube_size, s)) return 1;
-  JH_CHECK_HIP(hipStreamSynchronize(s));
-  return 0;
+  JH_REQUIRE(workspace_dev && workspace_bytes >= 0, "workspace (see jh_softargmax_workspace_bytes)");
+  Carver c(workspace_dev, (size_t)workspace_bytes);
+  SoftWs w;
+  carve_softargmax(c, t, joints, gh, &w);
+  JH_REQUIRE(c.fits(), "workspace smaller than jh_softargmax_workspace_bytes()");
+  if (launch_to_channel_last(v2v_out_dev, w.x, s)) return 1;
+  return launch_softargmax(w.x.p, center3d_dev, w.partial, w.pmax, points_dev, conf_dev,
+                           heatmap_final_dev, t, joints, w.x.Cp, gh, grid_spacing, roi_cube_size, s);
 }
 
 int jh_reproject_point(const float* points_dev, int npoints, int cams, const float* cam_dev,
@@ -158,22 +211,27 @@ int jh_reproject_point(const float* points_dev, int npoints, int cams, const flo
                                static_cast<hipStream_t>(stream));
 }
 
+int64_t jh_reconstruct_workspace_bytes(int cams) {
+  Carver c(nullptr, 0);
+  ReconWs w;
+  return (int64_t)carve_reconstruct(c, cams, &w);
+}
+
 int jh_reconstruct_point(const float* points2d_dev, const float* maxvals_dev, int cams,
                          const float* cam_dev, const float* intr_dev, const float* dist_dev,
-                         float* point3d_dev, void* stream) {
+                         float* point3d_dev, void* workspace_dev, int64_t workspace_bytes,
+                         void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
-  JH_REQUIRE(cams <= 64, "at most 64 cameras");
-  Scratch sc;
-  float* det; int *c3i, *chm, *valid;
-  if (sc.get(reinterpret_cast<void**>(&det), (size_t)cams * 3 * sizeof(float))) return 1;
-  if (sc.get(reinterpret_cast<void**>(&c3i), 3 * sizeof(int))) return 1;
-  if (sc.get(reinterpret_cast<void**>(&chm), (size_t)cams * 2 * sizeof(int))) return 1;
-  if (sc.get(reinterpret_cast<void**>(&valid), sizeof(int))) return 1;
-  hipLaunchKernelGGL(pack_det_kernel, dim3(1), dim3(64), 0, s, points2d_dev, maxvals_dev, det, cams);
-  if (launch_triangulate(det, cam_dev, intr_dev, dist_dev, point3d_dev, c3i, chm, valid, 1, cams,
-                         1.f, 1.f, 1.f, 0, 1 << 20, 1 << 20, s)) return 1;
-  JH_CHECK_HIP(hipStreamSynchronize(s));
-  return 0;
+  JH_REQUIRE(cams >= 1 && cams <= 64, "at most 64 cameras");
+  JH_REQUIRE(workspace_dev && workspace_bytes >= 0, "workspace (see jh_reconstruct_workspace_bytes)");
+  Carver c(workspace_dev, (size_t)workspace_bytes);
+  ReconWs w;
+  carve_reconstruct(c, cams, &w);
+  JH_REQUIRE(c.fits(), "workspace smaller than jh_reconstruct_workspace_bytes()");
+  hipLaunchKernelGGL(pack_det_kernel, dim3(1), dim3(64), 0, s, points2d_dev, maxvals_dev, w.det, cams);
+  JH_CHECK_HIP(hipGetLastError());
+  return launch_triangulate(w.det, cam_dev, intr_dev, dist_dev, point3d_dev, w.c3i, w.chm, w.valid, 1,
+                            cams, 1.f, 1.f, 1.f, 0, 1 << 20, 1 << 20, s);
 }
 
 }  // extern "C"

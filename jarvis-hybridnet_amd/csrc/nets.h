@@ -90,9 +90,13 @@ struct Ref {
 class EffTrackPlan : public Plan {
  public:
   // size: 0 small, 1 medium, 2 large.  N images of H x W (multiples of 64).
-  int build(const ParamMap& pm, const std::string& prefix, int size, int J, int N, int H, int W);
+  // want_res1: also compute res1 = final_conv1(first_conv(..)) (model.py:128), which the
+  // inference path never reads (hybridnet/model.py:57-58, jarvis3D.py:147)
+  int build(const ParamMap& pm, const std::string& prefix, int size, int J, int N, int H, int W,
+            bool want_res1 = false);
   Act input;     // [N][H][W][8]   normalised image, channel-last
   Act heat;      // [N][H/2][W/2][Jp]  res2 (ConvTranspose output)
+  Act res1;      // [N][H/4][W/4][Jp]  final_conv1 output (only with want_res1)
   int J = 0;
 
  private:

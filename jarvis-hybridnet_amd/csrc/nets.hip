@@ -363,7 +363,7 @@ int EffTrackPlan::node(const ParamMap& pm, const std::string& cp, int n_in, cons
 // EfficientTrackBackbone.forward, model.py:114-130 (res2 branch only: the
 // final_conv1 branch is dead on the inference path, model.py:57-58 / jarvis3D.py:147)
 int EffTrackPlan::build(const ParamMap& pm, const std::string& pre, int size, int joints, int N,
-                        int H, int W) {
+                        int H, int W, bool want_res1) {
   JH_REQUIRE(size >= 0 && size < 3, "model size");
   JH_REQUIRE(H % 64 == 0 && W % 64 == 0, "image side must be a multiple of 64");
   const SizeSpec& ss = kSizes[size];
@@ -457,6 +457,11 @@ int EffTrackPlan::build(const ParamMap& pm, const std::string& pre, int size, in
   if (node(pm, pre + "first_conv.", 3, hin, hmodes, w, ACT_NONE, p3.a, ss.head, &mid)) return 1;
   // first_conv's InstanceNorm is applied by deconv1 while it stages its operand
   if (new_act(N, 1, mid.a.H * 2, mid.a.W * 2, J, &heat)) return 1;
+  if (want_res1) {     // res1 = final_conv1(res1), model.py:128 (3x3, no bias, no norm)
+    if (new_act(N, 1, mid.a.H, mid.a.W, J, &res1)) return 1;
+    if (add_conv(pm, conv_desc(2, 3, 1, 1, ss.head, J), pre + "final_conv1.weight", "", false, mid.a,
+                 res1, nullptr, false, nullptr, mid.st, mid.inv, ACT_NONE)) return 1;
+  }
   if (J == 1) {
     // one output channel: vector-ALU kernel instead of a 16-wide MFMA column block
     const float* wh = nullptr;

@@ -23,6 +23,16 @@ new design for the 8 x MI355X node:
 submit() / flush() pipeline consecutive time batches so that the bulk exchange of one
 batch runs under the CenterDetect stage of the next; step() is submit() + flush().
 
+three_d='rank0' is the literal placement of BASELINE.json's north star / configs[3]:
+"RCCL all-gather of heatmaps, 3D stage on rank 0" -- the heatmaps of ALL frames are
+all-gathered, rank 0 alone runs reprojection + V2V + soft-argmax for the whole time batch
+and the (T, J, 4) results are broadcast.  It is Amdahl-bound by construction (V2V is 64 % of
+the FLOPs of a frame at configs[2]), which is why the default shards
+the 3D stage by frame; bench.py reports both.
+
+`comm` is the object the collectives are called on (default: torch.distributed).  Tests
+inject an in-process communicator to run several emulated ranks on one GPU.
+
 `stages` is any object with the four methods used below, which is what lets the
 world_size-2 gloo test on CPU drive this file with the oracle as compute.
 """
@@ -52,12 +62,23 @@ def frame_range(time_batch, rank, world):
 
 class ShardedPredictor:
     def __init__(self, stages, *, num_cameras, num_joints, time_batch, heat_shape, rank, world,
-                 device, exchange="alltoall", group=None):
-        """heat_shape = (h, w, Jp) of one camera's channel-last heatmap."""
+                 device, exchange="alltoall", group=None, three_d="sharded", comm=None):
+        """heat_shape = (h, w, Jp) of one camera's channel-last heatmap.
+        three_d: 'sharded' (rank r runs the 3D stage of frames [r*T/N, (r+1)*T/N)) or 'rank0'
+        (rank 0 runs it for all T frames; `stages` of rank 0 must then be built for
+        time_batch_3d = T)."""
+        assert three_d in ("sharded", "rank0") and exchange in ("alltoall", "allgather")
         self.st, self.C, self.J, self.T = stages, num_cameras, num_joints, time_batch
-        self.rank, self.world, self.group, self.exchange = rank, world, group, exchange
+        self.rank, self.world, self.group = rank, world, group
+        self.three_d = three_d
+        # the rank-0 placement needs every frame's heatmaps on rank 0: the all-gather
+        self.exchange = exchange = "allgather" if three_d == "rank0" else exchange
+        self.comm = comm if comm is not None else dist
         self.cam_lo, self.Cloc = camera_range(num_cameras, rank, world)
-        self.t_lo, self.T3 = frame_range(time_batch, rank, world)
+        if three_d == "rank0":
+            self.t_lo, self.T3 = 0, time_batch
+        else:
+            self.t_lo, self.T3 = frame_range(time_batch, rank, world)
         f32 = dict(device=device, dtype=torch.float32)
         self.det_local = torch.empty((self.T, self.Cloc, 3), **f32)
         # gather outputs are allocated in the "concatenated along dim 0" form that both
@@ -68,10 +89,11 @@ class ShardedPredictor:
             self.heat_recv = torch.empty((world * self.T3, self.Cloc) + tuple(heat_shape), **f32)
         else:
             self.heat_recv = torch.empty((world * self.T, self.Cloc) + tuple(heat_shape), **f32)
-        self.res_local = torch.empty((self.T3, self.J, 4), **f32)
-        self.res_all = torch.empty((world * self.T3, self.J, 4), **f32)
-        self.valid_local = torch.empty((self.T3,), device=device, dtype=torch.int32)
-        self.valid_all = torch.empty((world * self.T3,), device=device, dtype=torch.int32)
+        self.res_local = torch.zeros((self.T3, self.J, 4), **f32)
+        self.valid_local = torch.zeros((self.T3,), device=device, dtype=torch.int32)
+        n_res = self.T3 if three_d == "rank0" else world * self.T3
+        self.res_all = torch.empty((n_res, self.J, 4), **f32)
+        self.valid_all = torch.empty((n_res,), device=device, dtype=torch.int32)
         self._pending = None                     # exchange of the time batch in flight
 
     def step(self, frames_local):
@@ -88,18 +110,18 @@ class ShardedPredictor:
         """Start time batch i+1; returns the results of batch i (None on the first call)."""
         W, Cl = self.world, self.Cloc
         self.st.stage_center(frames_local, self.det_local)
-        dist.all_gather_into_tensor(self.det_gather, self.det_local, group=self.group)
+        self.comm.all_gather_into_tensor(self.det_gather, self.det_local, group=self.group)
         det_all = (self.det_gather.view(W, self.T, Cl, 3).permute(1, 0, 2, 3)
                    .reshape(self.T, self.C, 3).contiguous())
         prev = self._finish()
         self.st.stage_keypoints(frames_local, det_all, self.heat_local)
         if self.exchange == "alltoall":
             # block r of the send buffer = my cameras' heatmaps of rank r's frames
-            self._pending = dist.all_to_all_single(self.heat_recv, self.heat_local,
-                                                   group=self.group, async_op=True)
-        else:
-            self._pending = dist.all_gather_into_tensor(self.heat_recv, self.heat_local,
+            self._pending = self.comm.all_to_all_single(self.heat_recv, self.heat_local,
                                                         group=self.group, async_op=True)
+        else:
+            self._pending = self.comm.all_gather_into_tensor(self.heat_recv, self.heat_local,
+                                                             group=self.group, async_op=True)
         return prev
 
     def flush(self):
@@ -117,14 +139,32 @@ class ShardedPredictor:
         else:
             mine = self.heat_recv.view((W, self.T, Cl) + self.heat_recv.shape[2:])[
                 :, self.t_lo:self.t_lo + T3]
+        if self.three_d == "rank0":
+            if self.rank == 0:
+                self._run_3d(mine)
+            # results of the whole time batch from rank 0 to everybody
+            self.comm.broadcast(self.res_local, self._global_rank0(), group=self.group)
+            self.comm.broadcast(self.valid_local, self._global_rank0(), group=self.group)
+            res = self.res_local.clone()
+            return res[..., :3], res[..., 3], self.valid_local.clone()
+        self._run_3d(mine)
+        self.comm.all_gather_into_tensor(self.res_all, self.res_local, group=self.group)
+        self.comm.all_gather_into_tensor(self.valid_all, self.valid_local, group=self.group)
+        res = self.res_all.reshape(self.T, self.J, 4).clone()      # the buffers are reused
+        return res[..., :3], res[..., 3], self.valid_all.reshape(self.T).clone()
+
+    def _run_3d(self, mine):
         # (world, T3, Cloc, ...) -> (T3, C, ...): camera c = source_rank * Cloc + local camera
+        T3 = self.T3
         heat_all = mine.permute(1, 0, 2, 3, 4, 5).reshape((T3, self.C) + mine.shape[3:]).contiguous()
         pts = torch.empty((T3, self.J, 3), device=heat_all.device)
         conf = torch.empty((T3, self.J), device=heat_all.device)
         self.st.stage_3d(heat_all, self.t_lo, pts, conf, self.valid_local)
         self.res_local[..., :3] = pts
         self.res_local[..., 3] = conf
-        dist.all_gather_into_tensor(self.res_all, self.res_local, group=self.group)
-        dist.all_gather_into_tensor(self.valid_all, self.valid_local, group=self.group)
-        res = self.res_all.reshape(self.T, self.J, 4).clone()      # the buffers are reused
-        return res[..., :3], res[..., 3], self.valid_all.reshape(self.T).clone()
+
+    def _global_rank0(self):
+        """broadcast() takes the GLOBAL rank of the source: rank 0 of this group."""
+        if self.group is None or self.comm is not dist:
+            return 0
+        return dist.get_global_rank(self.group, 0)

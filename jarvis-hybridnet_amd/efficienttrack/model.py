@@ -15,11 +15,11 @@ from .._params import NativeModule, register_params, flat_state
 
 
 class _Plan:
-    def __init__(self, params, prefix, size_id, joints, shape):
+    def __init__(self, params, prefix, size_id, joints, shape, want_res1):
         self.handle = ctypes.c_void_p()
         n, _, h, w = shape
         N.check(N.lib().jh_efftrack_create(params.handle, prefix.encode(), size_id, joints, n, h,
-                                           w, ctypes.byref(self.handle)))
+                                           w, int(want_res1), ctypes.byref(self.handle)))
 
     def close(self):
         if self.handle and N is not None and N._lib is not None:
@@ -39,20 +39,27 @@ class EfficientTrackBackbone(NativeModule):
         self.cfg = cfg
         self.model_size = model_size
         self.output_channels = output_channels
+        # res1 = final_conv1(first_conv(..)) (model.py:128) is part of the (res1, res2) contract
+        # of the reference's trt_mode seam but never read on the inference path; set to False
+        # to skip its convolution (forward then returns (None, res2))
+        self.compute_res1 = True
         register_params(self, arch.efficienttrack_params(model_size, output_channels), "ones1d")
 
     def forward(self, inputs):
-        """inputs (N,3,H,W) fp32 on the GPU -> (res1, res2).  res1 (the
-        `final_conv1` branch, model.py:128) is never consumed on the inference
-        path (hybridnet/model.py:57-58, jarvis3D.py:147) and is returned as None."""
+        """inputs (N,3,H,W) fp32 on the GPU -> (res1 (N,J,H/4,W/4), res2 (N,J,H/2,W/2)),
+        model.py:126-130."""
         x = N.dev(inputs)
-        key = tuple(x.shape)
+        key = tuple(x.shape) + (bool(self.compute_res1),)
         plan = self._plans.get(key)
         if plan is None:
             params = N.Params(flat_state(self))
-            plan = _Plan(params, "", arch.SIZE_IDS[self.model_size], self.output_channels, key)
+            plan = _Plan(params, "", arch.SIZE_IDS[self.model_size], self.output_channels,
+                         tuple(x.shape), self.compute_res1)
             self._plans[key] = plan
-        out = torch.empty((x.shape[0], self.output_channels, x.shape[2] // 2, x.shape[3] // 2),
-                          device=x.device, dtype=torch.float32)
-        N.check(N.lib().jh_efftrack_forward(plan.handle, N.ptr(x), N.ptr(out), N.stream()))
-        return None, out
+        j, n, h, w = self.output_channels, x.shape[0], x.shape[2], x.shape[3]
+        res2 = torch.empty((n, j, h // 2, w // 2), device=x.device, dtype=torch.float32)
+        res1 = torch.empty((n, j, h // 4, w // 4), device=x.device, dtype=torch.float32) \
+            if self.compute_res1 else None
+        N.check(N.lib().jh_efftrack_forward(plan.handle, N.ptr(x), N.ptr(res1), N.ptr(res2),
+                                            N.stream()))
+        return res1, res2

@@ -8,7 +8,7 @@ V2V, soft-argmax -- no intermediate ever leaves the GPU.
 import torch
 
 from .. import _native as N
-from .._params import NativeModule, flat_state
+from .._params import NativeModule, flat_state, weights_fingerprint
 from .._predictor import NativePredictor
 from ..efficienttrack.model import EfficientTrackBackbone
 from .repro_layer import ReprojectionLayer
@@ -32,9 +32,10 @@ class HybridNetBackbone(NativeModule):
         self.v2vNet = V2VNet(cfg.KEYPOINTDETECT.NUM_JOINTS, cfg.KEYPOINTDETECT.NUM_JOINTS)
 
     def _predictor(self, batch, bbox):
-        key = (batch, bbox)
+        key = (batch, bbox, weights_fingerprint(self))     # reloads of effTrack / v2vNet count
         pr = self._plans.get(key)
         if pr is None:
+            self._invalidate()                              # stale plans of older weights
             c = self.cfg
             pr = NativePredictor(
                 None, flat_state(self), num_cameras=c.HYBRIDNET.NUM_CAMERAS,

@@ -22,11 +22,13 @@ class ReprojectionLayer(nn.Module):
         G = self.grid_size
         vol = torch.empty((1, J, G, G, G), device=hm.device, dtype=torch.float32)
         idx = torch.empty((C, G, G, G), device=hm.device, dtype=torch.int32) if want_idx else None
+        ws = N.workspace(N.lib().jh_reproject_workspace_bytes(C, J, hs, G), hm.device)
         N.check(N.lib().jh_reproject_forward(
             N.ptr(hm), C, J, hs, N.ptr(N.dev(center[0], torch.int32)),
             N.ptr(N.dev(centerHM[0], torch.int32)), N.ptr(N.dev(cameraMatrices[0])),
             N.ptr(N.dev(intrinsicMatrices[0])), N.ptr(N.dev(distortionCoefficients[0])), G,
-            float(self.grid_spacing), N.ptr(vol), N.ptr(idx), N.stream()))
+            float(self.grid_spacing), N.ptr(vol), N.ptr(idx), ws.data_ptr(), ws.numel(),
+            N.stream()))
         return vol, idx
 
     def forward(self, heatmaps, center, centerHM, cameraMatrices, intrinsicMatrices,

@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from .. import _native as N
-from .._params import flat_state
+from .._params import flat_state, weights_fingerprint
 from .._predictor import NativePredictor
 from ..efficienttrack.efficienttrack import EfficientTrack
 from ..hybridnet.hybridnet import HybridNet
@@ -48,8 +48,22 @@ class JarvisPredictor3D(nn.Module):
             center_model=c.CENTERDETECT.MODEL_SIZE, kp_model=c.KEYPOINTDETECT.MODEL_SIZE,
             time_batch=time_batch, cam_lo=cam_lo, cam_n=cam_n)
 
+    def _fresh_cache(self):
+        """Native predictors hold packed copies of the weights: drop them when any of the
+        sub-modules has been (re)loaded since they were built (load_state_dict into
+        centerDetect / hybridNet / hybridNet.effTrack / hybridNet.v2vNet)."""
+        fp = weights_fingerprint(self.centerDetect, self.hybridNet)
+        if fp != getattr(self, "_native_fp", None):
+            for pr in self._native.values():
+                for q in getattr(pr, "preds", [pr]):
+                    q.close()
+            self._native = {}
+            self._native_fp = fp
+        return self._native
+
     def native(self, img_h, img_w, time_batch=1, cam_lo=0, cam_n=None):
         """The native predictor for a frame size (built on first use)."""
+        self._fresh_cache()
         key = (img_h, img_w, time_batch, cam_lo, cam_n)
         pr = self._native.get(key)
         if pr is None:
@@ -61,6 +75,7 @@ class JarvisPredictor3D(nn.Module):
         MultiStreamPredictor: independent time batches in flight on `streams` HIP streams (the
         throughput form, see _predictor.MultiStreamPredictor)."""
         from .._predictor import MultiStreamPredictor
+        self._fresh_cache()
         key = ("streams", img_h, img_w, time_batch, streams)
         msp = self._native.get(key)
         if msp is None:

@@ -89,10 +89,11 @@ class ReprojectionTool(nn.Module):
         pts = N.dev(points)
         C = pts.shape[1]
         out = torch.empty(3, device=pts.device, dtype=torch.float32)
+        ws = N.workspace(N.lib().jh_reconstruct_workspace_bytes(C), pts.device)
         N.check(N.lib().jh_reconstruct_point(
             N.ptr(pts), N.ptr(N.dev(maxvals.reshape(-1))), C, N.ptr(N.dev(self.cameraMatrices)),
             N.ptr(N.dev(self.intrinsicMatrices)), N.ptr(N.dev(self.distortionCoefficients)),
-            N.ptr(out), N.stream()))
+            N.ptr(out), ws.data_ptr(), ws.numel(), N.stream()))
         return out
 
 

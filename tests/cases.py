@@ -4,6 +4,7 @@ Every input is re-derived from integers below, so the golden files only carry
 reference OUTPUTS.  Names follow BASELINE.json's configs where they apply:
 cfg2 = 4 cameras 640x512 / 48^3 grid, cfg3 = 12 cameras 1280x1024 / 64^3 grid.
 """
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -65,6 +66,17 @@ PREDICTOR_CASES = {
     "cfg2_none": dict(C=4, J=23, roi=96, spacing=2, bbox=256, center_size=256,
                       W=640, H=512, focal=900.0, cseed=50, hseed=51, fseed=53,
                       deconv_std=0.05, expect_none=True),
+    # the frames of cfg2 quantised to uint8 BGR (C,H,W,3) as the video
+    # decoder delivers them; the reference sees the driver's conversion of those bytes
+    # (prediction/predict3D.py:79-80)
+    "cfg2_u8": dict(C=4, J=23, roi=96, spacing=2, bbox=256, center_size=256,
+                    W=640, H=512, focal=900.0, cseed=50, hseed=51, fseed=58, u8=True),
+    # BASELINE configs[4]: 16 cameras 1280x1024, 30 keypoints, 96^3 grid; two subjects
+    # (`cfg5`, `cfg5_b`) form the T = 2 "batched multi-subject" case
+    "cfg5": dict(C=16, J=30, roi=192, spacing=2, bbox=256, center_size=256,
+                 W=1280, H=1024, focal=1800.0, cseed=54, hseed=55, fseed=56),
+    "cfg5_b": dict(C=16, J=30, roi=192, spacing=2, bbox=256, center_size=256,
+                   W=1280, H=1024, focal=1800.0, cseed=54, hseed=55, fseed=57),
 }
 
 
@@ -132,8 +144,15 @@ def predictor_inputs(tag):
     sd_c = S.efficienttrack_weights("small", 1, c["cseed"], deconv_std=std)
     sd_h = S.hybridnet_weights("small", c["J"], c["hseed"])
     imgs, joints, centre = S.blob_frames(calib, c["W"], c["H"], c["J"], c["fseed"])
-    return dict(sd_center=sd_c, sd_hybrid=sd_h, imgs=imgs, cam=calib[0],
-                intr=calib[1], dist=calib[2], joints=joints, centre=centre)
+    out = dict(sd_center=sd_c, sd_hybrid=sd_h, imgs=imgs, cam=calib[0],
+               intr=calib[1], dist=calib[2], joints=joints, centre=centre)
+    if c.get("u8"):
+        # bytes as decoded (BGR, HWC) and the reference driver's conversion of them,
+        # evaluated literally (jarvis/prediction/predict3D.py:79-80)
+        u8 = (imgs.permute(0, 2, 3, 1)[..., [2, 1, 0]] * 255).round().to(torch.uint8).contiguous()
+        out["u8"] = u8
+        out["imgs"] = (u8.float().permute(0, 3, 1, 2)[:, [2, 1, 0]] / 255.).contiguous()
+    return out
 
 
 # JarvisPredictor2D: one camera of the cfg2 rig, 12 joints
@@ -155,3 +174,19 @@ def predictor2d_inputs(tag):
     sd_k = S.efficienttrack_weights("small", c["J"], c["kseed"])
     imgs, _, _ = S.blob_frames(calib, c["W"], c["H"], 23, c["fseed"])
     return dict(sd_center=sd_c, sd_kp=sd_k, img=imgs[c["cam"]:c["cam"] + 1].contiguous())
+
+
+def analysis_samples(num_joints=23, n=5, cams=2):
+    """Seeded stand-ins for Dataset3D analysis samples and the predictions a predictor returns
+    for them (frame set 2 is `not detected`).  Shared by tests/golden/make_golden.py (which runs the reference's
+    analyze_validation_data on them) and tests/test_io_formats.py."""
+    g = torch.Generator().manual_seed(7)
+    samples, preds = [], []
+    for i in range(n):
+        imgs = (torch.rand((cams, 8, 10, 3), generator=g) * 255).double().numpy()
+        kp = (torch.rand((num_joints, 3), generator=g) * 200 - 100).double().numpy()
+        samples.append([imgs, kp, np.zeros((cams, 2), dtype=int), np.zeros(3), np.zeros(1),
+                        np.zeros(1), np.zeros(1), np.zeros(1), "calibA", "Frame_%03d.jpg" % i])
+        preds.append(None if i == 2 else
+                     (torch.rand((1, num_joints, 3), generator=g) * 200 - 100).float())
+    return samples, preds

@@ -457,7 +457,65 @@ def case_csv():
     print("wrote data3D_expected.csv (%d bytes)" % len(buf.getvalue()))
 
 
-ALL = dict(calibration=case_calibration, csv=case_csv, predictor2d=case_predictor2d, state_spec=case_state_spec, efficienttrack=case_efficienttrack,
+def case_analysis():
+    """analysis/analyze.py:22-96 run for real with its collaborators (project manager,
+    Dataset3D, predictor, calibration loader) replaced by seeded stand-ins: the three CSV
+    files it writes are the wire-format fixture for jarvis_hybridnet_amd.analysis."""
+    import shutil
+    import jarvis.analysis.analyze as A
+    J = 23
+    samples, preds = cases.analysis_samples(J)
+    out_root = tempfile.mkdtemp()
+
+    class FakeProject:
+        parent_dir = out_root
+        cfg = R.ns(PROJECTS_ROOT_PATH="projects", KEYPOINTDETECT=R.ns(NUM_JOINTS=J),
+                   DATALOADER_NUM_WORKERS=0)
+
+        def load(self, name):
+            return True
+
+        def get_cfg(self):
+            return self.cfg
+
+    class FakeDataset(torch.utils.data.Dataset):
+        image_ids = list(range(len(samples)))
+
+        def __init__(self, **kw):
+            pass
+
+        def __len__(self):
+            return len(samples)
+
+        def __getitem__(self, i):
+            return samples[i]
+
+    class FakePredictor:
+        def __init__(self, *a):
+            self.i = 0
+
+        def __call__(self, imgs, camM, K, D):
+            assert imgs.dtype == torch.float32 and imgs.shape[1] == 3
+            self.i += 1
+            return preds[self.i - 1], None
+    tool = R.ns(cameraMatrices=torch.zeros(2, 4, 3), intrinsicMatrices=torch.zeros(2, 3, 3),
+                distortionCoefficients=torch.zeros(2, 1, 5))
+    A.ProjectManager, A.Dataset3D, A.JarvisPredictor3D = FakeProject, FakeDataset, FakePredictor
+    A.load_reprojection_tools = lambda cfg, cameras_to_use=None: {"calibA": tool}
+    real_loader = A.DataLoader
+    A.DataLoader = lambda ds, **kw: real_loader(ds, **dict(kw, pin_memory=False))
+    A.analyze_validation_data("golden")
+    adir = os.path.join(out_root, "projects", "golden", "analysis")
+    run = os.path.join(adir, os.listdir(adir)[0])
+    dst = os.path.join(HERE, "analysis")
+    os.makedirs(dst, exist_ok=True)
+    for f in ("frame_names.csv", "points_HybridNet.csv", "points_GroundTruth.csv"):
+        shutil.copy(os.path.join(run, f), os.path.join(dst, f))
+        print("wrote analysis/%s (%d bytes)" % (f, os.path.getsize(os.path.join(dst, f))))
+    shutil.rmtree(out_root)
+
+
+ALL = dict(analysis=case_analysis, calibration=case_calibration, csv=case_csv, predictor2d=case_predictor2d, state_spec=case_state_spec, efficienttrack=case_efficienttrack,
            reprojection=case_reprojection, v2v=case_v2v, geometry=case_geometry,
            hybridnet=case_hybridnet, predictor=case_predictor)
 

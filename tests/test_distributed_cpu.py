@@ -89,7 +89,7 @@ class OracleStages:
                 pts[i], conf[i], valid[i] = p[0], cf[0], self.state[("valid", t)]
 
 
-def _worker(rank, world, port, exchange, q, T=T):
+def _worker(rank, world, port, exchange, q, T=T, three_d="sharded"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -98,7 +98,7 @@ def _worker(rank, world, port, exchange, q, T=T):
     st = OracleStages(calib, sd_c, sd_h, lo, n)
     sh = ShardedPredictor(st, num_cameras=C, num_joints=J, time_batch=T,
                           heat_shape=(BBOX // 2, BBOX // 2, JP), rank=rank, world=world,
-                          device="cpu", exchange=exchange)
+                          device="cpu", exchange=exchange, three_d=three_d)
     mine = frames[:, lo:lo + n].contiguous()
     pts, conf, valid = sh.step(mine)
     # pipelined form: batch B (frames in reverse order) is submitted while batch A is in
@@ -118,17 +118,22 @@ def _worker(rank, world, port, exchange, q, T=T):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange,world", [("alltoall", 2), ("allgather", 2), ("alltoall", 4)])
-def test_camera_sharded_equals_single_process(exchange, world):
+@pytest.mark.parametrize("exchange,world,three_d", [("alltoall", 2, "sharded"),
+                                                    ("allgather", 2, "sharded"),
+                                                    ("alltoall", 4, "sharded"),
+                                                    ("allgather", 2, "rank0")])
+def test_camera_sharded_equals_single_process(exchange, world, three_d):
     """world 4 = one camera per rank, the group size the 4- and 8-GPU runs use (12 cameras -> 3
-    per rank there)."""
+    per rank there).  three_d='rank0' = the literal placement of BASELINE configs[3]: heatmaps
+    all-gathered, 3D stage on rank 0, results broadcast."""
     T = 2 if world == 2 else 4
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, exchange, q, T)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, exchange, q, T, three_d))
+             for r in range(world)]
     for p in procs:
         p.start()
     pts, conf, valid = q.get(timeout=240)
@@ -160,3 +165,32 @@ def test_plan_groups():
         lo = [camera_range(12, r, w) for r in range(w)]
         assert sum(n for _, n in lo) == 12 and [a for a, _ in lo] == [r * (12 // w) for r in range(w)]
         assert [frame_range(64, r, w)[0] for r in range(w)] == [r * (64 // w) for r in range(w)]
+
+
+@pytest.mark.parametrize("exchange,three_d", [("alltoall", "sharded"), ("allgather", "rank0")])
+def test_local_comm_matches_gloo_semantics(exchange, three_d):
+    """tests/local_comm.py (threads + copies; what the one-GPU multi-rank emulation of
+    tests/test_hip_predictor.py uses instead of RCCL) drives ShardedPredictor to the same result
+    as the single-process oracle, like the gloo processes above."""
+    from tests.local_comm import LocalWorld
+    world, Tn = 2, 2
+    calib, sd_c, sd_h, frames = make_inputs(Tn)
+
+    def rank_fn(rank, comm):
+        lo, n = camera_range(C, rank, world)
+        st = OracleStages(calib, sd_c, sd_h, lo, n)
+        sh = ShardedPredictor(st, num_cameras=C, num_joints=J, time_batch=Tn,
+                              heat_shape=(BBOX // 2, BBOX // 2, JP), rank=rank, world=world,
+                              device="cpu", exchange=exchange, three_d=three_d, comm=comm)
+        return sh.step(frames[:, lo:lo + n].contiguous())
+    res = LocalWorld(world).run(rank_fn)
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)                       # every rank holds the full result
+    pts, conf, valid = res[0]
+    for t in range(Tn):
+        with torch.no_grad():
+            rp, rc = O.predictor3d_forward(sd_c, sd_h, frames[t], *calib, **KW)
+        assert int(valid[t]) == (rp is not None)
+        if rp is not None:
+            assert (pts[t] - rp[0]).abs().max().item() < 1e-3
+            assert (conf[t] - rc[0]).abs().max().item() < 1e-5

@@ -43,13 +43,21 @@ def test_hybridnet_backbone(tag, golden):
     check_summary(g, tag + ".heatmap_final", fin.cpu(), rtol=1e-3, atol=1e-3)
 
 
-@pytest.mark.parametrize("tag", ["cfg2", "cfg3", "cfg2_none"])
+@pytest.mark.parametrize("tag", ["cfg2", "cfg3", "cfg2_none", "cfg2_u8", "cfg5"])
 def test_predictor3d(tag, golden):
+    """JarvisPredictor3D.forward vs the imported reference's output on the same input
+    (tests/golden/predictor.npz).  cfg2_u8: the HIP path is fed the uint8 BGR bytes
+    (forward_uint8), the reference the driver's conversion of the same bytes
+    (predict3D.py:79-80).  cfg5 = BASELINE configs[4]: 16 cameras, 30 keypoints, 96^3."""
     from jarvis_hybridnet_amd.prediction.jarvis3D import JarvisPredictor3D
     c = cases.PREDICTOR_CASES[tag]
     inp = cases.predictor_inputs(tag)
     pred = JarvisPredictor3D(make_cfg(c, c["center_size"]), inp["sd_center"], inp["sd_hybrid"])
-    pts, conf = pred(cuda(inp["imgs"]), cuda(inp["cam"]), cuda(inp["intr"]), cuda(inp["dist"]))
+    calib = (cuda(inp["cam"]), cuda(inp["intr"]), cuda(inp["dist"]))
+    if c.get("u8"):
+        pts, conf = pred.forward_uint8(cuda(inp["u8"]), *calib)
+    else:
+        pts, conf = pred(cuda(inp["imgs"]), *calib)
     torch.cuda.synchronize()
     g = golden("predictor")
     dbg = pred.native(c["H"], c["W"]).debug("cuda")
@@ -144,26 +152,239 @@ def test_sharded_stages_emulated_two_ranks():
         assert ep < 1e-4 and ec < 1e-6
 
 
-def test_predictor3d_uint8_ingest():
+def test_predictor3d_uint8_ingest(golden):
     """frames as uint8 BGR (C,H,W,3) straight from the decoder.
-    Must equal the fp32 path fed the reference driver's conversion
-    (predict3D.py:79-80) bit for bit -- the conversion is the same arithmetic, only
-    done inside the resize / crop kernels."""
+    Checker = the CPU oracle run on THIS host on the reference driver's conversion
+    `u8.float().permute(0,3,1,2)[:, [2,1,0]] / 255.` (predict3D.py:79-80), plus the committed
+    fixture (`cfg2_u8`, the imported reference's output in the build container).  The fp32
+    HIP entry fed the same converted tensor is a third, looser cross-check."""
+    from jarvis_hybridnet_amd import synthetic as S
+    from jarvis_hybridnet_amd.prediction.jarvis3D import JarvisPredictor3D
+    from oracle import hybridnet_oracle as O
+    c = cases.PREDICTOR_CASES["cfg2_u8"]
+    inp = cases.predictor_inputs("cfg2_u8")
+    u8 = inp["u8"]
+    pred = JarvisPredictor3D(make_cfg(c, c["center_size"]), inp["sd_center"], inp["sd_hybrid"])
+    dev = [cuda(inp[k]) for k in ("cam", "intr", "dist")]
+    p1, c1 = pred.forward_uint8(cuda(u8), *dev)
+    torch.cuda.synchronize()
+    dbg = {k: v.clone() for k, v in pred.native(c["H"], c["W"]).debug("cuda").items()}
+    assert p1 is not None
+    inter = {}
+    with torch.no_grad():
+        rp, rc = O.predictor3d_forward(inp["sd_center"], inp["sd_hybrid"], inp["imgs"], inp["cam"],
+                                       inp["intr"], inp["dist"], center_size=c["center_size"],
+                                       bbox=c["bbox"], roi_cube_size=c["roi"],
+                                       grid_spacing=c["spacing"], mean=S.MEAN, std=S.STD, chunk=5,
+                                       intermediates=inter)
+    # integer path vs the host oracle: exact
+    assert torch.equal(dbg["det"][0, :, :2].cpu().long(), inter["preds"].reshape(c["C"], 2))
+    assert torch.equal(dbg["center_hm"][0].cpu(), inter["center_hm"])
+    assert torch.equal(dbg["center3d_int"][0].cpu(), inter["center3d"].int())
+    g = golden("predictor")
+    e_host, e_fix = max_err(p1, rp), max_err(p1, torch.from_numpy(g["cfg2_u8.points3D"]))
+    ec = max_err(c1, torch.from_numpy(g["cfg2_u8.confidences"]))
+    report("predictor3d_u8", points_mm_vs_host_oracle=e_host, points_mm_vs_fixture=e_fix, conf=ec)
+    assert e_fix < 1e-3 and ec < 1e-4, "uint8 ingest must match the reference within 1e-3 mm"
+    assert e_host < 5e-2           # host CPU != fixture CPU: see DESIGN.md section 1
+    # the fp32 entry point fed the converted tensor (x * (1/255) on the GPU vs x / 255 on the
+    # CPU differ by <= 1 ulp per sample)
+    p0, c0 = pred(cuda(inp["imgs"]), *dev)
+    torch.cuda.synchronize()
+    assert max_err(p0, p1) < 1e-3 and max_err(c0, c1) < 1e-5
+    pts, conf, valid = pred.forward_batch(cuda(torch.stack([u8, u8])), *dev)
+    torch.cuda.synchronize()
+    assert int(valid.sum()) == 2 and (pts[1] - p1[0]).abs().max().item() < 1e-4
+
+
+def test_predictor3d_multi_subject_cfg5(golden):
+    """BASELINE configs[4] 'batched multi-subject stream': T = 2 independent subjects of the
+    16-camera / 30-keypoint / 96^3 rig in ONE call; row t must equal the reference's batch-1
+    forward on subject t (the reference is batch-1 only, repro_layer.py:113-117, so the golden
+    for T > 1 is the loop over subjects: SURVEY 7.2-7)."""
+    from jarvis_hybridnet_amd.prediction.jarvis3D import JarvisPredictor3D
+    c = cases.PREDICTOR_CASES["cfg5"]
+    a, b = cases.predictor_inputs("cfg5"), cases.predictor_inputs("cfg5_b")
+    pred = JarvisPredictor3D(make_cfg(c, c["center_size"]), a["sd_center"], a["sd_hybrid"])
+    dev = [cuda(a[k]) for k in ("cam", "intr", "dist")]
+    pts, conf, valid = pred.forward_batch(cuda(torch.stack([a["imgs"], b["imgs"]])), *dev)
+    torch.cuda.synchronize()
+    dbg = pred.native(c["H"], c["W"], time_batch=2).debug("cuda")
+    g = golden("predictor")
+    assert valid.tolist() == [1, 1]
+    for t, tag in enumerate(("cfg5", "cfg5_b")):
+        assert torch.equal(dbg["det"][t, :, :2].cpu().long(),
+                           torch.from_numpy(g[tag + ".preds"]).reshape(c["C"], 2))
+        assert torch.equal(dbg["center_hm"][t].cpu(), torch.from_numpy(g[tag + ".center_hm"]))
+        assert torch.equal(dbg["center3d_int"][t].cpu(), torch.from_numpy(g[tag + ".center3d"]).int())
+        ep = max_err(pts[t], torch.from_numpy(g[tag + ".points3D"])[0])
+        ec = max_err(conf[t], torch.from_numpy(g[tag + ".confidences"])[0])
+        report("predictor3d_cfg5_T2", subject=tag, points_mm=ep, conf=ec)
+        assert ep < 1e-3 and ec < 1e-4
+
+
+@pytest.mark.parametrize("mode", ["alltoall", "allgather", "rank0"])
+def test_sharded_cfg3_four_ranks(mode, golden):
+    """BASELINE configs[3] on ONE GPU: the 12-camera rig sharded 3 cameras per rank over FOUR
+    emulated ranks, T = 4 frames, through the real ShardedPredictor (distributed.py) with an
+    in-process communicator (tests/local_comm.py: copies instead of RCCL).  `rank0` is the
+    literal placement of configs[3] (heatmaps all-gathered, 3D stage on rank 0).  Frame 0 is
+    fixture case cfg3 (the reference's output); all frames must equal the unsharded forward."""
+    from jarvis_hybridnet_amd import synthetic as S
+    from jarvis_hybridnet_amd._predictor import NativePredictor
+    from jarvis_hybridnet_amd.distributed import ShardedPredictor, camera_range
+    from tests.local_comm import LocalWorld
+    c = cases.PREDICTOR_CASES["cfg3"]
+    inp = cases.predictor_inputs("cfg3")
+    calib = (inp["cam"], inp["intr"], inp["dist"])
+    T, C, J, world = 4, c["C"], c["J"], 4
+    frames = cuda(torch.stack([inp["imgs"]] + [S.blob_frames(calib, c["W"], c["H"], J, 60 + t)[0]
+                                               for t in range(1, T)]))
+    common = dict(num_cameras=C, num_joints=J, center_size=c["center_size"], bbox=c["bbox"],
+                  roi_cube_size=c["roi"], grid_spacing=c["spacing"], img_h=c["H"], img_w=c["W"],
+                  mean=S.MEAN, std=S.STD, time_batch=T)
+    dev = [cuda(t) for t in calib]
+    full = NativePredictor(inp["sd_center"], inp["sd_hybrid"], **common)
+    full.set_calibration(*dev)
+    rp, rc, rv = [t.clone() for t in full.forward(frames)]
+    torch.cuda.synchronize()
+    three_d = "rank0" if mode == "rank0" else "sharded"
+    preds = []
+    for r in range(world):
+        lo, n = camera_range(C, r, world)
+        t3 = T if three_d == "rank0" else T // world
+        p = NativePredictor(inp["sd_center"], inp["sd_hybrid"], time_batch_3d=t3, cam_lo=lo,
+                            cam_n=n, **common)
+        p.set_calibration(*dev)
+        preds.append(p)
+
+    def rank_fn(rank, comm):
+        torch.cuda.set_device(0)
+        p = preds[rank]
+        lo, n = camera_range(C, rank, world)
+        sh = ShardedPredictor(p, num_cameras=C, num_joints=J, time_batch=T,
+                              heat_shape=(p.Hh, p.Hh, p.Jp), rank=rank, world=world, device="cuda",
+                              exchange="allgather" if mode == "rank0" else mode, three_d=three_d,
+                              comm=comm)
+        mine = frames[:, lo:lo + n].contiguous()
+        first = sh.step(mine)
+        assert sh.submit(mine) is None             # pipelined form gives the same rows
+        again = sh.flush()
+        torch.cuda.synchronize()
+        return first, again
+    res = LocalWorld(world).run(rank_fn)
+    torch.cuda.synchronize()
+    for r in range(world):
+        (pts, conf, valid), again = res[r]
+        assert torch.equal(valid, rv)
+        ep, ec = max_err(pts, rp), max_err(conf, rc)
+        report("sharded_cfg3_4ranks", mode=mode, rank=r, points_mm=ep, conf=ec)
+        assert ep < 1e-4 and ec < 1e-6
+        assert max_err(again[0], pts) < 1e-4
+    gold = torch.from_numpy(golden("predictor")["cfg3.points3D"])[0]
+    e0 = max_err(res[0][0][0][0], gold)
+    report("sharded_cfg3_4ranks", mode=mode, frame0_vs_reference_fixture_mm=e0)
+    assert e0 < 1e-3
+
+
+def test_center3d_truncation_seed_sweep():
+    """`center3D.int()` (jarvis3D.py:183) truncates a float32 SVD result, so whenever a centre
+    coordinate lies within rounding noise of an integer the reference's own output flips by
+    1 mm between CPU models.  Over 64 seeds of the cfg2 rig: count the
+    frames whose integer centre (or centre argmax) differs from the oracle run on THIS host and
+    require that every such frame sits inside the reference's instability band; all other
+    frames must agree with the oracle closely."""
+    from jarvis_hybridnet_amd import synthetic as S
+    from jarvis_hybridnet_amd.prediction.jarvis3D import JarvisPredictor3D
+    from oracle import hybridnet_oracle as O
+    c = cases.PREDICTOR_CASES["cfg2"]
+    inp = cases.predictor_inputs("cfg2")
+    calib = (inp["cam"], inp["intr"], inp["dist"])
+    pred = JarvisPredictor3D(make_cfg(c, c["center_size"]), inp["sd_center"], inp["sd_hybrid"])
+    dev = [cuda(t) for t in calib]
+    seeds = list(range(1000, 1064))
+    n_valid = n_int_flip = n_arg_flip = 0
+    worst_pts, worst_c3 = 0.0, 0.0
+    torch.set_num_threads(max(1, min(16, len(__import__("os").sched_getaffinity(0)))))
+    for seed in seeds:
+        imgs = S.blob_frames(calib, c["W"], c["H"], c["J"], seed)[0]
+        pts, conf = pred(cuda(imgs), *dev)
+        torch.cuda.synchronize()
+        dbg = {k: v.clone() for k, v in pred.native(c["H"], c["W"]).debug("cuda").items()}
+        inter = {}
+        with torch.no_grad():
+            rp, rc = O.predictor3d_forward(inp["sd_center"], inp["sd_hybrid"], imgs, *calib,
+                                           center_size=c["center_size"], bbox=c["bbox"],
+                                           roi_cube_size=c["roi"], grid_spacing=c["spacing"],
+                                           mean=S.MEAN, std=S.STD, chunk=5, intermediates=inter)
+        assert (pts is None) == (rp is None), "validity differs at seed %d" % seed
+        if rp is None:
+            continue
+        n_valid += 1
+        preds_ref = inter["preds"].reshape(c["C"], 2)
+        if not torch.equal(dbg["det"][0, :, :2].cpu().long(), preds_ref):
+            # a centre argmax flipped: only legitimate when the reference's top-2 are a tie
+            hm = inter["center_heatmap"].flatten(1)
+            top2 = hm.topk(2, dim=1)[0]
+            bad = (dbg["det"][0, :, :2].cpu().long() != preds_ref).any(1)
+            margin = ((top2[:, 0] - top2[:, 1]) / top2[:, 0].abs())[bad].max().item()
+            assert margin < 1e-4, "argmax differs at seed %d with a clear margin %g" % (seed, margin)
+            n_arg_flip += 1
+            continue
+        c3_ref = inter["center3d"]
+        worst_c3 = max(worst_c3, (dbg["center3d"][0].cpu() - c3_ref).abs().max().item())
+        diff = dbg["center3d_int"][0].cpu() != c3_ref.int()
+        if bool(diff.any()):
+            # every differing coordinate must be within 0.02 mm of an integer in the oracle
+            dist_to_int = (c3_ref - c3_ref.round()).abs()[diff].max().item()
+            assert dist_to_int < 0.02, "center3D.int() differs at seed %d, %g mm from an integer" % (
+                seed, dist_to_int)
+            n_int_flip += 1
+            continue
+        if not torch.equal(dbg["center_hm"][0].cpu(), inter["center_hm"]):
+            # crop centres are truncated projections of center3D: same argument, in pixels
+            uv = O.reproject_point(c3_ref.unsqueeze(0), *calib)
+            d = (uv - uv.round()).abs()[dbg["center_hm"][0].cpu() != inter["center_hm"]].max().item()
+            assert d < 0.02, "centerHM differs at seed %d, %g px from an integer" % (seed, d)
+            n_int_flip += 1
+            continue
+        worst_pts = max(worst_pts, max_err(pts, rp))
+    report("center3d_seed_sweep", seeds=len(seeds), valid=n_valid, center_int_flips=n_int_flip,
+           argmax_flips=n_arg_flip, flip_fraction=(n_int_flip + n_arg_flip) / max(1, n_valid),
+           worst_points_mm_vs_host_oracle=worst_pts, worst_center3d_mm=worst_c3)
+    assert n_valid >= 48
+    assert worst_c3 < 0.02            # fp64 Jacobi vs fp32 SVD of the reference
+    assert worst_pts < 5e-2           # host-CPU oracle (see DESIGN.md): index flips move points by ~0.02
+    assert n_int_flip + n_arg_flip <= 0.1 * n_valid
+
+
+def test_weight_reload_invalidates_native_predictors():
+    """Packed weights are rebuilt after load_state_dict into any sub-module (the cache of
+    JarvisPredictor3D is keyed by frame shape; a stale entry would keep the old weights)."""
+    from jarvis_hybridnet_amd import synthetic as S
     from jarvis_hybridnet_amd.prediction.jarvis3D import JarvisPredictor3D
     c = cases.PREDICTOR_CASES["cfg2"]
     inp = cases.predictor_inputs("cfg2")
-    u8 = (inp["imgs"].permute(0, 2, 3, 1)[..., [2, 1, 0]] * 255).round().to(torch.uint8).contiguous()
-    ref_in = cuda(u8).float().permute(0, 3, 1, 2)[:, [2, 1, 0]] / 255.
     pred = JarvisPredictor3D(make_cfg(c, c["center_size"]), inp["sd_center"], inp["sd_hybrid"])
     dev = [cuda(inp[k]) for k in ("cam", "intr", "dist")]
-    p0, c0 = pred(ref_in.contiguous(), *dev)
-    p1, c1 = pred.forward_uint8(cuda(u8), *dev)
+    imgs = cuda(inp["imgs"])
+    p0, _ = pred(imgs, *dev)
+    other = S.hybridnet_weights("small", c["J"], 99)
+    pred.hybridNet.load_state_dict(other, strict=True)
+    p1, _ = pred(imgs, *dev)
+    fresh = JarvisPredictor3D(make_cfg(c, c["center_size"]), inp["sd_center"], other)
+    p2, _ = fresh(imgs, *dev)
     torch.cuda.synchronize()
-    assert p0 is not None and p1 is not None
-    assert torch.equal(p0, p1) and torch.equal(c0, c1)
-    pts, conf, valid = pred.forward_batch(cuda(torch.stack([u8, u8])), *dev)
+    assert max_err(p1, p2) < 1e-4 and max_err(p0, p1) > 1e-2
+    # ... and through a child module only
+    v2v = {k[len("v2vNet."):]: v for k, v in inp["sd_hybrid"].items() if k.startswith("v2vNet.")}
+    pred.hybridNet.v2vNet.load_state_dict(v2v, strict=True)
+    mixed = dict(other)
+    mixed.update({"v2vNet." + k: v for k, v in v2v.items()})
+    p3, _ = pred(imgs, *dev)
+    p4, _ = JarvisPredictor3D(make_cfg(c, c["center_size"]), inp["sd_center"], mixed)(imgs, *dev)
     torch.cuda.synchronize()
-    assert int(valid.sum()) == 2 and (pts[1] - p0[0]).abs().max().item() < 1e-4
+    assert max_err(p3, p4) < 1e-4 and max_err(p3, p1) > 1e-3
 
 
 @pytest.mark.parametrize("tag", list(cases.PREDICTOR2D_CASES))
@@ -224,6 +445,21 @@ def test_predict3d_frames_writes_csv(tmp_path, golden):
     n = predict3D_frames(pred, [u8] * 7, *dev, cfg, str(tmp_path / "ms"), time_batch=2, streams=3)
     rows3 = list(csv.reader(open(tmp_path / "ms" / "data3D.csv")))
     assert n == 7 and len(rows3) == 9 and all(r == rows[3] for r in rows3[2:])
+    # DISTINCT frame sets per group (a stale or recycled input buffer of a group in flight on a
+    # side stream would show up as a wrong row): 9 different frame sets, streams=3 vs streams=1
+    from jarvis_hybridnet_amd import synthetic as S
+    calib = (inp["cam"], inp["intr"], inp["dist"])
+    sets = [(S.blob_frames(calib, c["W"], c["H"], c["J"], 70 + i)[0].permute(0, 2, 3, 1)[..., [2, 1, 0]]
+             * 255).round().to(torch.uint8).numpy() for i in range(9)]
+    n1 = predict3D_frames(pred, sets, *dev, cfg, str(tmp_path / "d1"), time_batch=2, streams=1)
+    n3 = predict3D_frames(pred, sets, *dev, cfg, str(tmp_path / "d3"), time_batch=2, streams=3)
+    r1 = list(csv.reader(open(tmp_path / "d1" / "data3D.csv")))
+    r3 = list(csv.reader(open(tmp_path / "d3" / "data3D.csv")))
+    assert n1 == n3 == 9 and len(r1) == len(r3) == 11
+    assert len({tuple(r) for r in r1[2:]}) == 9          # the nine rows really differ
+    for a, b in zip(r1[2:], r3[2:]):
+        va, vb = [float(x) for x in a], [float(x) for x in b]
+        assert max(abs(x - y) for x, y in zip(va, vb)) < 1e-3
 
 
 def test_error_paths_are_loud():
@@ -253,6 +489,16 @@ def test_error_paths_are_loud():
     v2.load_state_dict(S.v2v_weights(3, 2), strict=True)
     with pytest.raises(RuntimeError, match="multiple of 4"):
         v2(torch.zeros(1, 3, 18, 18, 18, device="cuda"))
+    # frames of the wrong dtype / shape never reach the raw-pointer boundary
+    from jarvis_hybridnet_amd._predictor import NativePredictor
+    c = cases.PREDICTOR_CASES["cfg2"]
+    npred = NativePredictor(S.efficienttrack_weights("small", 1, 50), S.hybridnet_weights("small", 3, 51),
+                            num_cameras=2, num_joints=3, center_size=128, bbox=128, roi_cube_size=32,
+                            grid_spacing=2, img_h=256, img_w=320, mean=S.MEAN, std=S.STD)
+    with pytest.raises(RuntimeError, match="dtype"):
+        npred.forward(torch.zeros(1, 2, 3, 256, 320, device="cuda", dtype=torch.float64))
+    with pytest.raises(RuntimeError, match="shape"):
+        npred.forward(torch.zeros(1, 2, 3, 256, 300, device="cuda"))
     # after an error the library keeps working
     y = v2(torch.rand(1, 3, 16, 16, 16, device="cuda"))
     torch.cuda.synchronize()

@@ -25,15 +25,19 @@ def test_efficienttrack(tag):
     sd = S.efficienttrack_weights(size, J, wseed)
     x = cases.efftrack_input(N, hw, xseed)
     with torch.no_grad():
-        ref = O.efficienttrack_forward(sd, x, size, want_res1=False)[1]
+        ref1, ref = O.efficienttrack_forward(sd, x, size, want_res1=True)
     net = EfficientTrackBackbone(None, size, J)
     net.load_state_dict(sd, strict=True)
-    res1, res2 = net(cuda(x))
+    res1, res2 = net(cuda(x))                 # the (res1, res2) tuple of model.py:126-130
     torch.cuda.synchronize()
-    assert res1 is None
-    e = rel_err(res2, ref)
-    report("efficienttrack", tag=tag, rel=e, absmax=float(ref.abs().max()))
-    assert e < 1e-3
+    e, e1 = rel_err(res2, ref), rel_err(res1, ref1)
+    report("efficienttrack", tag=tag, rel=e, rel_res1=e1, absmax=float(ref.abs().max()))
+    assert e < 1e-3 and e1 < 1e-3
+    assert tuple(res1.shape) == tuple(ref1.shape)
+    net.compute_res1 = False                   # inference form: the dead branch is skipped
+    none1, again = net(cuda(x))
+    torch.cuda.synchronize()
+    assert none1 is None and rel_err(again, res2) < 1e-5
     # argmax of every heatmap channel agrees (integer path of the 2D detector)
     a = res2.cpu().flatten(2).argmax(2)
     b = ref.flatten(2).argmax(2)
@@ -65,8 +69,10 @@ def test_v2v_and_tail(tag, golden):
     fin = torch.empty((1, J, Gh, Gh, Gh), device="cuda")
     pts = torch.empty((1, J, 3), device="cuda")
     conf = torch.empty((1, J), device="cuda")
+    ws = N.workspace(N.lib().jh_softargmax_workspace_bytes(1, J, Gh), "cuda")
     N.check(N.lib().jh_softargmax(out.data_ptr(), 1, J, Gh, 2.0, float(G * 2), cuda(center).data_ptr(),
-                                  fin.data_ptr(), pts.data_ptr(), conf.data_ptr(), N.stream()))
+                                  fin.data_ptr(), pts.data_ptr(), conf.data_ptr(), ws.data_ptr(),
+                                  ws.numel(), N.stream()))
     torch.cuda.synchronize()
     ep, ec, ef = max_err(pts, rpts), max_err(conf, rconf), rel_err(fin, rfin)
     report("v2v", tag=tag, rel=e, points_mm=ep, conf=ec, final_rel=ef)
@@ -138,3 +144,60 @@ def test_geometry(tag, golden):
     report("geometry", tag=tag, reconstruct_mm=e_rec, reproject_px=e_rep)
     assert e_rec < 1e-3          # fp64 eigen-solve vs the reference's fp32 SVD
     assert e_rep < 1e-3
+
+
+def test_submodule_path_graph_capture(golden):
+    """The stand-alone operators behind the reference-shaped sub-modules (ReprojectionLayer,
+    ReprojectionTool.reconstructPoint / reprojectPoint, the soft-argmax tail) neither allocate
+    nor synchronise: they take a caller-provided workspace (jh_*_workspace_bytes), so the whole
+    sub-module path can be captured into a hipGraph and replayed.  A hipMalloc or
+    hipStreamSynchronize inside any of them would abort the capture."""
+    from types import SimpleNamespace as NS
+    from jarvis_hybridnet_amd import _native as N
+    from jarvis_hybridnet_amd import synthetic as S
+    from jarvis_hybridnet_amd.hybridnet.repro_layer import ReprojectionLayer
+    from jarvis_hybridnet_amd.utils.reprojection import ReprojectionTool
+    C, J, G, spacing, bbox, W, H, focal, seed = cases.REPRO_CASES["cfg2"]
+    inp = cases.repro_inputs("cfg2")
+    cfg = NS(HYBRIDNET=NS(GRID_SPACING=spacing, ROI_CUBE_SIZE=G * spacing, NUM_CAMERAS=C),
+             KEYPOINTDETECT=NS(BOUNDING_BOX_SIZE=bbox))
+    layer = ReprojectionLayer(cfg)
+    args = [cuda(inp[k]) for k in ("hm_pad", "center3d", "center_hm", "cam", "intr", "dist")]
+    args[1], args[2] = args[1].int().contiguous(), args[2].int().contiguous()
+    pts2d, maxvals, p3d = cases.geom_inputs("c4")
+    tool = ReprojectionTool()
+    cam, intr, dist = S.ring_calibration(4, 640, 512, 900.0)
+    tool.cameraMatrices, tool.intrinsicMatrices, tool.distortionCoefficients = cuda(cam), cuda(intr), cuda(dist)
+    d_pts2d, d_maxv, d_p3d = cuda(pts2d), cuda(maxvals.reshape(-1)), cuda(p3d)
+    Gh = G // 2
+    x = cuda(torch.rand(1, J, Gh, Gh, Gh, generator=torch.Generator().manual_seed(5)) * 3)
+    c3 = cuda(torch.tensor([[35, -58, 549]], dtype=torch.int32))
+
+    def run():
+        vol = layer(*args)
+        rec = tool.reconstructPoint(d_pts2d, d_maxv)
+        rep = tool.reprojectPoint(d_p3d)
+        ws = N.workspace(N.lib().jh_softargmax_workspace_bytes(1, J, Gh), "cuda")
+        pts = torch.empty((1, J, 3), device="cuda")
+        conf = torch.empty((1, J), device="cuda")
+        N.check(N.lib().jh_softargmax(x.data_ptr(), 1, J, Gh, float(spacing), float(G * spacing),
+                                      c3.data_ptr(), None, pts.data_ptr(), conf.data_ptr(),
+                                      ws.data_ptr(), ws.numel(), N.stream()))
+        return vol, rec, rep, pts, conf
+    # one workspace serves the three operators in stream order; size it for the largest first
+    N.workspace(max(N.lib().jh_reproject_workspace_bytes(C, J, bbox // 2 + 2, G),
+                    N.lib().jh_softargmax_workspace_bytes(1, J, Gh)), "cuda")
+    eager = [t.clone() for t in run()]
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        captured = run()
+    for t in captured:
+        t.zero_()
+    torch.cuda.synchronize()
+    graph.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(eager, captured):
+        assert torch.equal(a, b) or (a - b).abs().max().item() <= 1e-5 * a.abs().max().item()
+    g = golden("geometry")
+    assert (captured[1].cpu() - torch.from_numpy(g["c4.reconstruct"])).abs().max() < 1e-3

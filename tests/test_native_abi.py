@@ -25,8 +25,25 @@ def test_library_exports_header_symbols():
     for name in names:
         assert hasattr(lib, name), "libjarvis_hip.so lacks " + name
     assert names == N.symbols(), "ctypes table and header disagree"
-    assert lib.jh_abi_version() == 1
+    assert lib.jh_abi_version() == N.ABI_VERSION == 2
     assert lib.jh_last_error() is not None
+
+
+def test_header_is_valid_c_and_links(tmp_path):
+    """include/jarvis_hip.h in a plain C translation unit (gcc -std=c11 -Wall -Werror), with
+    static asserts on the jh_predictor_config layout that _native.PredictorConfig mirrors;
+    the program is linked against libjarvis_hip.so and calls the GPU-free entry points."""
+    import ctypes
+    import subprocess
+    N.lib()
+    exe = str(tmp_path / "abi_smoke")
+    libdir = os.path.dirname(N.LIB_PATH)
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-pedantic",
+                    "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "abi_smoke.c"),
+                    "-o", exe, "-L", libdir, "-ljarvis_hip", "-Wl,-rpath," + libdir,
+                    "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert out.split() == ["abi", str(N.ABI_VERSION), "config", str(ctypes.sizeof(N.PredictorConfig))]
 
 
 def test_missing_library_fails_loudly(monkeypatch):

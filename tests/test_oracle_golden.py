@@ -99,7 +99,7 @@ def test_hybridnet(golden, tag):
     check_summary(g, tag + ".heatmaps_padded", hm, **TOL)
 
 
-@pytest.mark.parametrize("tag", ["cfg2", "cfg2_none"])
+@pytest.mark.parametrize("tag", ["cfg2", "cfg2_none", "cfg2_u8", "cfg5"])
 def test_predictor(golden, tag):
     c = cases.PREDICTOR_CASES[tag]
     inp = cases.predictor_inputs(tag)
