@@ -302,9 +302,12 @@ def test_center3d_truncation_seed_sweep():
     calib = (inp["cam"], inp["intr"], inp["dist"])
     pred = JarvisPredictor3D(make_cfg(c, c["center_size"]), inp["sd_center"], inp["sd_hybrid"])
     dev = [cuda(t) for t in calib]
+    from jarvis_hybridnet_amd.hybridnet.repro_layer import ReprojectionLayer
+    layer = ReprojectionLayer(make_cfg(c))
+    G, hs = int(c["roi"] / c["spacing"]), c["bbox"] // 2 + 2
     seeds = list(range(1000, 1064))
-    n_valid = n_int_flip = n_arg_flip = 0
-    worst_pts, worst_c3 = 0.0, 0.0
+    n_valid = n_int_flip = n_arg_flip = n_idx_seeds = 0
+    worst_pts, worst_c3, worst_dirty, worst_frac = 0.0, 0.0, 0.0, 0.0
     torch.set_num_threads(max(1, min(16, len(__import__("os").sched_getaffinity(0)))))
     for seed in seeds:
         imgs = S.blob_frames(calib, c["W"], c["H"], c["J"], seed)[0]
@@ -348,13 +351,34 @@ def test_center3d_truncation_seed_sweep():
             assert d < 0.02, "centerHM differs at seed %d, %g px from an integer" % (seed, d)
             n_int_flip += 1
             continue
-        worst_pts = max(worst_pts, max_err(pts, rp))
+        # Same integer centre on both sides.  What is left is the reference's OWN host dependence:
+        # torch's CPU trilinear kernel differs in the last bit between CPU models, which flips a
+        # few gather indices of the oracle run here against the build-container reference that the
+        # HIP gather reproduces bit for bit (tests/test_hip_stages.py::test_reprojection).  Count
+        # those flips on identical inputs and hold frames without any to the 1e-3 mm bar.
+        c3i, chm = c3_ref.int()[None], inter["center_hm"][None]
+        idx = layer.gather_indices(cuda(inter["heatmaps_padded"]), cuda(c3i), cuda(chm),
+                                   dev[0][None], dev[1][None], dev[2][None]).cpu()
+        grid = O.reprojection_grid(c["roi"], c["spacing"]) + c3i[0]
+        ridx = O.reprojection_indices(grid, *calib, chm[0], hs, G)[0]
+        mism = int((idx != ridx).sum())
+        e = max_err(pts, rp)
+        worst_frac = max(worst_frac, mism / ridx.numel())
+        if mism == 0:
+            worst_pts = max(worst_pts, e)
+        else:
+            n_idx_seeds += 1
+            worst_dirty = max(worst_dirty, e)
+            assert e < 5e-3 + 0.02 * mism, "seed %d: %g mm with %d host index flips" % (seed, e, mism)
     report("center3d_seed_sweep", seeds=len(seeds), valid=n_valid, center_int_flips=n_int_flip,
            argmax_flips=n_arg_flip, flip_fraction=(n_int_flip + n_arg_flip) / max(1, n_valid),
-           worst_points_mm_vs_host_oracle=worst_pts, worst_center3d_mm=worst_c3)
+           worst_points_mm_clean_frames=worst_pts, worst_center3d_mm=worst_c3,
+           frames_with_host_index_flips=n_idx_seeds, worst_points_mm_those_frames=worst_dirty,
+           worst_host_index_flip_fraction=worst_frac)
     assert n_valid >= 48
     assert worst_c3 < 0.02            # fp64 Jacobi vs fp32 SVD of the reference
-    assert worst_pts < 5e-2           # host-CPU oracle: index flips move points by ~0.02
+    assert worst_pts < 1e-3           # frames on which host oracle == build-container reference
+    assert worst_frac < 1e-3
     assert n_int_flip + n_arg_flip <= 0.1 * n_valid
 
 
