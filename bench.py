@@ -4,21 +4,25 @@
 Metric (BASELINE.json): multi-view frames/s.  One "step" = one pass of the hot
 path (JarvisPredictor3D.forward: resize -> CenterDetect -> argmax ->
 triangulation -> crops -> KeypointDetect -> reprojection -> V2V -> soft-argmax)
-over one time batch of T independent synthetic multi-view frames that are
-already resident in HBM as fp32 (C,3,H,W) tensors (the API's input type).
-Workload = BASELINE.json configs[2]: 12 cameras 1280x1024, 23 keypoints, 64^3
-voxel grid, small/small models, fp32 (the reference's precision).
+over one time batch of T independent synthetic multi-view frames per HIP stream,
+frames already resident in HBM as fp32 (C,3,H,W) tensors (the API's input type).
+Default workload = BASELINE.json configs[2]: 12 cameras 1280x1024, 23 keypoints,
+64^3 voxel grid, small/small models, fp32 (the reference's precision).
+`--config cfg5` = configs[4] (16 cameras, 30 keypoints, 96^3), `--config cfg2` =
+configs[1]'s geometry in fp32.
 
     python bench.py --gpus N --steps K --warmup W
 
 N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL); cameras are
 sharded over the ranks (jarvis_hybridnet_amd/distributed.py).  Rank 0 prints ONE
-JSON line; `roofline` is measured live with HIP events around every launch of a
-profiled pass, `cpu_baseline` times the CPU oracle on the host cores (N = 1 only).
+JSON line.  `roofline` and `kernels` are measured live with HIP events around every
+launch of profiled passes on one stream; `cpu_baseline` times the CPU oracle on the
+host cores (N = 1 only).
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -28,11 +32,25 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 CONFIGS = {
-    "cfg3": dict(C=12, W=1280, H=1024, J=23, roi=128, spacing=2, bbox=256, center=256, focal=1800.0),
-    "cfg2": dict(C=4, W=640, H=512, J=23, roi=96, spacing=2, bbox=256, center=256, focal=900.0),
+    "cfg3": dict(C=12, W=1280, H=1024, J=23, roi=128, spacing=2, bbox=256, center=256, focal=1800.0,
+                 time_batch=32,
+                 metric="multi-view frames/s (12cam 1280x1024, 23kpt, 64^3 grid)",
+                 workload="BASELINE configs[2]: HybridNet 12-camera 1280x1024, 23 kpts, 64^3 grid, "
+                          "small/small"),
+    "cfg2": dict(C=4, W=640, H=512, J=23, roi=96, spacing=2, bbox=256, center=256, focal=900.0,
+                 time_batch=32,
+                 metric="multi-view frames/s (4cam 640x512, 23kpt, 48^3 grid)",
+                 workload="BASELINE configs[1] geometry in fp32: HybridNet 4-camera 640x512, 23 kpts, "
+                          "48^3 grid, small/small"),
+    "cfg5": dict(C=16, W=1280, H=1024, J=30, roi=192, spacing=2, bbox=256, center=256, focal=1800.0,
+                 time_batch=8,
+                 metric="multi-view frames/s (16cam 1280x1024, 30kpt, 96^3 grid)",
+                 workload="BASELINE configs[4]: HybridNet 16-camera 1280x1024, 30 kpts, 96^3 grid, "
+                          "small/small, batched multi-subject stream"),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_HBM_GBS = 8000.0
+PMC_TRAFFIC = os.path.join("profiles", "r02_pmc_traffic.json")
 
 
 def usable_cores():
@@ -48,21 +66,82 @@ def usable_cores():
     return n
 
 
+def executed_flops(name, flops):
+    """FLOPs the matrix cores really execute for a conv launch whose ALGORITHMIC
+    (direct-convolution, unpadded) count is `flops`: channel padding (input channels to 8,
+    output channels to 16) and, for the Winograd kernel, 12 instead of 27 multiplies per
+    output and channel pair (F(2x2,3x3) over (y,x) x 3 z taps)."""
+    try:
+        cin, cout = [int(v) for v in name.split("_")[-1].split("@")[0].split("x")]
+    except ValueError:
+        return flops
+    pad = (-(-cin // 8) * 8) * (-(-cout // 16) * 16) / float(cin * cout)
+    return flops * pad * (12.0 / 27.0 if "wino" in name else 1.0)
+
+
+def kernel_table(recs, passes, top=10):
+    """Per-kernel roofline rows from HIP-event records of `passes` profiled passes:
+    median duration per launch position, summed per kernel name."""
+    per_pass = len(recs) // passes
+    rows = {}
+    for i in range(per_pass):
+        name, _, fl, by = recs[i]
+        ms = statistics.median(recs[p * per_pass + i][1] for p in range(passes))
+        r = rows.setdefault(name, dict(ms=0.0, n=0, flops=0.0, bytes=0.0))
+        r["ms"] += ms
+        r["n"] += 1
+        r["flops"] += fl
+        r["bytes"] += by
+    total = sum(r["ms"] for r in rows.values())
+    out = []
+    for name, r in sorted(rows.items(), key=lambda kv: -kv[1]["ms"]):
+        s = r["ms"] * 1e-3
+        if r["flops"] > 0 and name.startswith("conv"):
+            ex = executed_flops(name, r["flops"])
+            row = dict(kernel=name, bound="mfma", achieved=ex / s / 1e12, peak=PEAK_F32_MFMA_TFLOPS,
+                       unit="TFLOP/s", frac=ex / s / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                       algorithmic_equiv=r["flops"] / s / 1e12)
+        else:
+            row = dict(kernel=name, bound="hbm", achieved=r["bytes"] / s / 1e9, peak=PEAK_HBM_GBS,
+                       unit="GB/s", frac=r["bytes"] / s / 1e9 / PEAK_HBM_GBS)
+        row.update(ms_per_step=r["ms"], launches_per_step=r["n"], avg_launch_ms=r["ms"] / r["n"],
+                   share_of_step=r["ms"] / total, algorithmic_flops_per_launch=r["flops"] / r["n"],
+                   algorithmic_bytes_per_launch=r["bytes"] / r["n"])
+        out.append(row)
+    return out[:top], total
+
+
+def percentiles(ms):
+    ms = sorted(ms)
+
+    def q(p):
+        return ms[min(len(ms) - 1, max(0, int(round(p * (len(ms) - 1)))))]
+    return dict(median=statistics.median(ms), p10=q(0.10), p90=q(0.90), n=len(ms))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--time-batch", type=int, default=None,
-                    help="multi-view frames per time batch (default: 32 per stream on one GPU, 64 per "
-                         "GPU when camera-sharded)")
+                    help="multi-view frames per time batch and HIP stream (default: 32 for cfg3 / cfg2, "
+                         "8 for cfg5); at N > 1 every rank carries this many whole frames of work")
     ap.add_argument("--streams", type=int, default=3,
                     help="single GPU: independent time batches in flight on that many HIP streams; one "
                          "step = one time batch per stream")
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
+    ap.add_argument("--model-size", default="small", choices=["small", "medium", "large"],
+                    help="EfficientTrack size of both 2D networks (small = the reference's default)")
     ap.add_argument("--exchange", default="alltoall", choices=["alltoall", "allgather"])
+    ap.add_argument("--three-d", default="sharded", choices=["sharded", "rank0"],
+                    help="multi-GPU placement of the 3D stage: frame-sharded over the ranks of a group "
+                         "(default) or all of it on rank 0 (the literal BASELINE configs[3] placement)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-uint8", action="store_true", help="skip the uint8-ingest side measurement")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary line (medium/medium models, SURVEY 8d)")
+    ap.add_argument("--no-side-legs", action="store_true", help="multi-GPU: skip rank0-3D and replicas legs")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph")
     ap.add_argument("--sharded-streams", type=int, default=2,
@@ -72,6 +151,7 @@ def main():
                     help="multi-GPU: do not overlap the heatmap exchange with the next step's 2D stage")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU (camera-sharded, RCCL) code path even with one rank")
+    ap.add_argument("--profile-passes", type=int, default=5)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -94,12 +174,13 @@ def main():
 
     from jarvis_hybridnet_amd import _native as N
     from jarvis_hybridnet_amd import synthetic as S
-    from jarvis_hybridnet_amd._predictor import NativePredictor
+    from jarvis_hybridnet_amd._predictor import MultiStreamPredictor, NativePredictor
 
     c = CONFIGS[args.config]
     if args.time_batch is None:
-        args.time_batch = 32
-    KS = max(1, args.sharded_streams) if (sharded and not args.no_pipeline) else 1
+        args.time_batch = c["time_batch"]
+    pipelined = sharded and not args.no_pipeline and args.three_d == "sharded"
+    KS = max(1, args.sharded_streams) if pipelined else 1
     K = KS if sharded else (1 if args.graph else max(1, args.streams))
     # Weak scaling: every rank always does the work of `--time-batch` whole frames
     # (T*C images of 2D work, T frames of 3D work).  Ranks form groups of `gs` GPUs
@@ -109,24 +190,28 @@ def main():
     grank, gidx = rank % gs, rank // gs
     T = args.time_batch * gs                       # frames per group and step
     calib = S.ring_calibration(c["C"], c["W"], c["H"], c["focal"])
-    sd_c = S.efficienttrack_weights("small", 1, 50)
-    sd_h = S.hybridnet_weights("small", c["J"], 51)
+    size = args.model_size
+    sd_c = S.efficienttrack_weights(size, 1, 50)
+    sd_h = S.hybridnet_weights(size, c["J"], 51)
     distinct = [S.blob_frames(calib, c["W"], c["H"], c["J"], 52 + i)[0] for i in range(min(T, 2))]
 
-    def device_frames(cam_lo, cam_n):
-        """(T, cam_n, 3, H, W) on the GPU, assembled there from the distinct frames so
-        the host never holds T copies (T = 64 frames per group at 8 GPUs)."""
+    def device_frames(cam_lo, cam_n, frames=T):
+        """(frames, cam_n, 3, H, W) on the GPU, assembled there from the distinct frames so
+        the host never holds T copies (T = 128 frames per group at 4 GPUs per group)."""
         base = torch.stack([d[cam_lo:cam_lo + cam_n] for d in distinct]).to(dev)
-        idx = torch.arange(T, device=dev) % len(distinct)
+        idx = torch.arange(frames, device=dev) % len(distinct)
         return base[idx].contiguous()
 
-    common = dict(num_cameras=c["C"], num_joints=c["J"], center_size=c["center"], bbox=c["bbox"],
-                  roi_cube_size=c["roi"], grid_spacing=c["spacing"], img_h=c["H"], img_w=c["W"],
-                  mean=S.MEAN, std=S.STD, time_batch=T)
+    def common_kw(model=size, frames=T):
+        return dict(num_cameras=c["C"], num_joints=c["J"], center_size=c["center"], bbox=c["bbox"],
+                    roi_cube_size=c["roi"], grid_spacing=c["spacing"], img_h=c["H"], img_w=c["W"],
+                    mean=S.MEAN, std=S.STD, time_batch=frames, center_model=model, kp_model=model)
+    common = common_kw()
+    calib_dev = [t.to(dev) for t in calib]
+    step_events = []                               # per stream: one event per step (timed region)
     if not sharded:
-        from jarvis_hybridnet_amd._predictor import MultiStreamPredictor
-        msp = MultiStreamPredictor(lambda: NativePredictor(sd_c, sd_h, **common), streams=K)
-        msp.set_calibration(*[t.to(dev) for t in calib])
+        msp = MultiStreamPredictor(lambda: NativePredictor(sd_c, sd_h, **common), streams=K, timing=True)
+        msp.set_calibration(*calib_dev)
         pred = msp.preds[0]                        # the per-kernel profile and the side legs use one
         fr = device_frames(0, c["C"])
         outs = [(torch.empty((T, c["J"], 3), device=dev), torch.empty((T, c["J"]), device=dev),
@@ -134,32 +219,45 @@ def main():
         out = outs[0]
         torch.cuda.synchronize()
 
-        def step():
+        def step(record=False):
             # one step = one time batch per stream (K * T frame sets)
-            res0 = None
             for i in range(K):
-                r = msp.forward(fr, outs[i]) if K > 1 else pred.forward(fr, outs[i])
-                res0 = r if i == 0 else res0
-            return res0
+                if K > 1:
+                    msp.forward(fr, outs[i])
+                    if record:
+                        step_events[i].append(msp.last_event)
+                else:
+                    pred.forward(fr, outs[i])
+                    if record:
+                        ev = torch.cuda.Event(enable_timing=True)
+                        ev.record()
+                        step_events[0].append(ev)
+            return outs
     else:
         from jarvis_hybridnet_amd.distributed import ShardedPredictor, camera_range
         groups = [dist.new_group(list(range(g * gs, (g + 1) * gs))) for g in range(n_groups)]
         cam_lo, cam_n = camera_range(c["C"], grank, gs)
         fr = device_frames(cam_lo, cam_n)
-        preds, shs = [], []
-        for _ in range(KS):
-            p_ = NativePredictor(sd_c, sd_h, time_batch_3d=T // gs, cam_lo=cam_lo, cam_n=cam_n, **common)
-            p_.set_calibration(*[t.to(dev) for t in calib])
-            preds.append(p_)
-            shs.append(ShardedPredictor(p_, num_cameras=c["C"], num_joints=c["J"], time_batch=T,
-                                        heat_shape=(p_.Hh, p_.Hh, p_.Jp), rank=grank, world=gs,
-                                        device=dev, exchange=args.exchange, group=groups[gidx]))
+
+        def make_sharded(three_d, count):
+            ps, ss = [], []
+            for _ in range(count):
+                t3 = T if three_d == "rank0" else T // gs
+                p_ = NativePredictor(sd_c, sd_h, time_batch_3d=t3, cam_lo=cam_lo, cam_n=cam_n, **common)
+                p_.set_calibration(*calib_dev)
+                ps.append(p_)
+                ss.append(ShardedPredictor(p_, num_cameras=c["C"], num_joints=c["J"], time_batch=T,
+                                           heat_shape=(p_.Hh, p_.Hh, p_.Jp), rank=grank, world=gs,
+                                           device=dev, exchange=args.exchange, group=groups[gidx],
+                                           three_d=three_d))
+            return ps, ss
+        preds, shs = make_sharded(args.three_d, KS)
         pred, sh = preds[0], shs[0]
         sh_streams = [torch.cuda.Stream() for _ in range(KS)]
         torch.cuda.synchronize()
 
-        def step():
-            return sh.step(fr)
+        def step(record=False):
+            return [sh.step(fr)]
 
     def barrier():
         if sharded:
@@ -167,8 +265,9 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(max(1, args.warmup)):
-        res = step()
-    run = step
+        step()
+    step_events = [[] for _ in range(K if not sharded else 1)]
+    run = (lambda: step(True)) if not sharded else step
     if args.graph and not sharded:
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
@@ -176,7 +275,7 @@ def main():
             step()
         run = g.replay
         run()
-    if sharded and not args.no_pipeline:
+    if pipelined:
         # consecutive time batches pipelined: the heatmap exchange of step i runs under the
         # CenterDetect stage of step i+1; K submits + the final flush = exactly K whole steps.
         # KS such pipelines run on KS HIP streams (every rank issues their collectives in the
@@ -190,10 +289,15 @@ def main():
                 with torch.cuda.stream(sh_streams[k]):
                     shs[k].submit(fr)
     barrier()
+    if not sharded and not args.graph:             # t = 0 marks for the per-step percentiles
+        for i in range(K):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(msp.streams[i] if K > 1 else torch.cuda.current_stream())
+            step_events[i].append(ev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run()
-    if sharded and not args.no_pipeline:
+    if pipelined:
         for k in range(KS):
             with torch.cuda.stream(sh_streams[k]):
                 shs[k].flush()
@@ -205,84 +309,88 @@ def main():
         dt = tt.item()
     res = step()
     torch.cuda.synchronize()
-    res = [r.clone() if torch.is_tensor(r) else r for r in res]      # `out` is reused below
-    valid = int(res[2].sum().item())
-    fps = T * K * n_groups * args.steps / dt
+    res = [[r.clone() for r in o] for o in res]    # the output buffers are reused below
+    valid = sum(int(o[2].sum().item()) for o in res) * (n_groups * K if sharded else 1)
+    frames_per_step = T * K * n_groups
+    fps = frames_per_step * args.steps / dt
 
     line = {
-        "metric": "multi-view frames/s (12cam 1280x1024, 23kpt, 64^3 grid)",
+        "metric": c["metric"],
         "value": fps, "unit": "multi-view frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic (seeded blob frames, ring calibration, random-init weights)",
-        "config": {"workload": "BASELINE configs[2]: HybridNet 12-camera 1280x1024, 23 kpts, "
-                               "64^3 grid, small/small" if args.config == "cfg3" else args.config,
+        "config": {"workload": c["workload"] if size == "small" else
+                   c["workload"].replace("small/small", "%s/%s" % (size, size)),
                    "cameras": c["C"], "frame": [c["H"], c["W"]], "joints": c["J"],
                    "grid": int(c["roi"] / c["spacing"]), "time_batch": T, "streams": K,
-                   "frames_per_step": T * K * n_groups, "valid_frames_last_step": valid,
+                   "frames_per_step": frames_per_step, "valid_frames_per_step": valid,
                    "parallelism": ("single GPU, %d time batches in flight on %d HIP streams" % (K, K))
                    if not sharded else
-                   "%d group(s) x %d GPUs: camera-sharded 2D (%d cams/GPU) + RCCL %s of "
-                   "heatmaps%s + frame-sharded 3D; %d such pipeline(s) per rank" % (
-                       n_groups, gs, c["C"] // gs, args.exchange,
-                       "" if args.no_pipeline else " (overlapped with the next step's CenterDetect)", KS),
+                   "%d group(s) x %d GPUs: camera-sharded 2D (%d cams/GPU) + RCCL %s of heatmaps%s + %s; "
+                   "%d such pipeline(s) per rank" % (
+                       n_groups, gs, c["C"] // gs, shs[0].exchange,
+                       " (overlapped with the next step's CenterDetect)" if pipelined else "",
+                       "3D stage on rank 0 of the group" if args.three_d == "rank0" else "frame-sharded 3D", KS),
                    "launches_per_step": int(pred.launches) * K, "launches_per_time_batch": int(pred.launches),
                    "hipgraph": bool(args.graph)},
     }
+    if not sharded and not args.graph and step_events[0]:
+        # distribution over the timed steps.  One sample = the time one stream needs
+        # for one time batch while the other streams' batches share the GPU (HIP events).
+        ms = []
+        for evs in step_events:
+            ms += [evs[i].elapsed_time(evs[i + 1]) for i in range(len(evs) - 1)]
+        p = percentiles(ms)
+        line["step_time_ms"] = dict(p, note="per time batch of %d frames on one of %d concurrent streams "
+                                    "(HIP events); frames/s = streams * time_batch / ms" % (T, K))
+        line["frames_per_s_median"] = K * T / p["median"] * 1e3
+        line["frames_per_s_p10_p90"] = [K * T / p["p90"] * 1e3, K * T / p["p10"] * 1e3]
 
+    P = max(1, args.profile_passes)
     if sharded and rank != 0:
-        for _ in range(3):                         # rank 0 profiles 3 steps: keep the collectives matched
+        for _ in range(P + 1):                     # rank 0 profiles P+1 steps: keep the collectives matched
             step()
     if rank == 0:
-        # ---- roofline of the dominant kernel, HIP events around every launch (at N > 1: rank 0's
-        # share of the camera-sharded step)
+        # ---- per-kernel roofline, HIP events around every launch of ONE stream's time batch
+        # (kernels timed alone; at N > 1: rank 0's share of the camera-sharded step).  Median
+        # over P passes per launch position, after one discarded profiled pass.
+        prof_fn = (lambda: step()) if sharded else (lambda: pred.forward(fr, out))
+        N.profile(prof_fn)
         recs = []
-        for _ in range(3):
-            recs += N.profile(step if sharded else (lambda: pred.forward(fr, out)))   # one stream: kernels timed alone
-        agg = {}
-        for name, ms, fl, by in recs:
-            a = agg.setdefault(name, [0.0, 0, fl, by])
-            a[0] += ms
-            a[1] += 1
-        total_ms = sum(a[0] for a in agg.values())
-        top = sorted(agg.items(), key=lambda kv: -kv[1][0])
-        name, (ms, cnt, fl, by) = top[0]
-        avg_s = ms / cnt * 1e-3
-        if fl > 0 and name.startswith("conv"):
-            line["roofline"] = {"kernel": name, "bound": "mfma", "achieved": fl / avg_s / 1e12,
-                                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                "frac": fl / avg_s / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                                "avg_launch_ms": ms / cnt, "launches_per_step": cnt // 3,
-                                "share_of_step": ms / total_ms}
-        else:
-            line["roofline"] = {"kernel": name, "bound": "hbm", "achieved": by / avg_s / 1e9,
-                                "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                "frac": by / avg_s / 1e9 / PEAK_HBM_GBS, "traffic": None,
-                                "avg_launch_ms": ms / cnt, "launches_per_step": cnt // 3,
-                                "share_of_step": ms / total_ms}
-        if "wino" in name:
-            # Winograd F(2x2,3x3) over (y,x) x direct z executes 12 instead of 27 multiplies per
-            # output and channel pair; `achieved` above is the ALGORITHMIC (direct-convolution)
-            # rate, so it may exceed the MFMA peak.  The matrix cores' own utilisation:
-            cin, cout = [int(v) for v in name.split("_")[2].split("@")[0].split("x")]
-            pad = ((cin + 7) // 8 * 8) * ((cout + 15) // 16 * 16) / float(cin * cout)
-            ex = line["roofline"]["achieved"] * 12.0 / 27.0 * pad
-            line["roofline"]["algorithm"] = ("Winograd F(2x2,3x3) x 3 z taps: 2.25x fewer multiplies than "
-                                             "the direct algorithm `achieved` is counted in")
-            line["roofline"]["mfma_executed"] = {"achieved": ex, "unit": "TFLOP/s",
-                                                 "frac": ex / PEAK_F32_MFMA_TFLOPS}
-        # HBM bytes of that kernel from the committed PMC passes (rocprofv3 cannot run
-        # inside this process), scaled to this run's time batch
+        for _ in range(P):
+            recs += N.profile(prof_fn)
+        table, total_ms = kernel_table(recs, P, int(os.environ.get("JH_BENCH_TOP", "10")))
+        top = table[0]
+        T_prof = T // gs if sharded else T
+        roof = {k: top[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms",
+                                    "launches_per_step", "share_of_step")}
+        roof["traffic"] = None
+        roof["time_batch"] = T_prof
+        if top["bound"] == "mfma":
+            roof["algorithmic_equiv"] = top["algorithmic_equiv"]
+            roof["note"] = ("achieved = FLOPs the matrix cores execute (channel padding included%s) / HIP-event "
+                            "duration; algorithmic_equiv = the same launch counted as the direct convolution it "
+                            "computes" % (", Winograd F(2x2,3x3) x 3 z taps: 12 of the direct algorithm's 27 "
+                                          "multiplies" if "wino" in top["kernel"] else ""))
+        roof["algorithmic_bytes"] = top["algorithmic_bytes_per_launch"]
+        # HBM bytes of that kernel: rocprofv3 cannot run inside this process, so the PMC passes
+        # (tools/pmc_traffic.sh: the same bench command under --pmc FETCH_SIZE / WRITE_SIZE) are
+        # committed under profiles/ and scaled to this run's time batch
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if name in pmc:
-                line["roofline"]["traffic"] = pmc[name]["hbm_bytes_per_launch"] * (T // gs if sharded else T) / pmc[name]["time_batch"]
-                line["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
-                line["roofline"]["algorithmic_bytes"] = by
-        except (OSError, ValueError):
+            pmc = json.load(open(os.path.join(ROOT, PMC_TRAFFIC)))
+            if top["kernel"] in pmc:
+                e = pmc[top["kernel"]]
+                roof["traffic"] = e["hbm_bytes_per_launch"] * T_prof / e["time_batch"]
+                roof["traffic_source"] = "%s (rocprofv3 --pmc passes of `%s`, time batch %d)" % (
+                    PMC_TRAFFIC, e.get("command", "bench.py"), e["time_batch"])
+        except (OSError, ValueError, KeyError):
             pass
-        line["kernel_breakdown_ms_per_step"] = {k: round(v[0] / 3, 4) for k, v in top[:int(os.environ.get("JH_BENCH_TOP", "12"))]}
-        line["kernel_time_ms_per_step"] = total_ms / 3
+        line["roofline"] = roof
+        line["kernels"] = [{k: (round(v, 5) if isinstance(v, float) else v) for k, v in row.items()
+                            if k not in ("algorithmic_flops_per_launch", "algorithmic_bytes_per_launch")}
+                           for row in table]
+        line["kernel_time_ms_per_time_batch"] = total_ms
 
     if rank == 0 and not sharded and not args.no_uint8:
         # ---- the same step fed uint8 BGR frames as the decoder delivers
@@ -333,8 +441,9 @@ def main():
                                 "frames_per_s_incl_pcie_h2d_serial": fps_pcie,
                                 "frames_per_s_incl_pcie_h2d_overlapped": fps_overlap,
                                 "bytes_per_frame": int(host[0].numel()),
-                                "note": "pinned host uint8 BGR -> HBM inside the timed region; "
+                                "note": "one stream; pinned host uint8 BGR -> HBM inside the timed region; "
                                         "overlapped = copy of batch i+1 on a second HIP stream"}
+        del bufs, dev_u8, host
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # ---- CPU baseline: the oracle (port of the reference) on the host cores,
@@ -343,7 +452,8 @@ def main():
         cores = usable_cores()
         torch.set_num_threads(cores)
         kw = dict(center_size=c["center"], bbox=c["bbox"], roi_cube_size=c["roi"],
-                  grid_spacing=c["spacing"], mean=S.MEAN, std=S.STD)
+                  grid_spacing=c["spacing"], mean=S.MEAN, std=S.STD, center_model=size, kp_model=size,
+                  chunk=5)
         with torch.no_grad():
             ref = O.predictor3d_forward(sd_c, sd_h, distinct[0], *calib, **kw)     # warm-up
             n, t0 = 0, time.perf_counter()
@@ -359,58 +469,123 @@ def main():
             # NOTE: torch's CPU kernels differ in the last bit between CPU models, which
             # flips a few reprojection gather indices of the reference itself (DESIGN.md,
             # "reproducibility of the reference"); the pinned comparison is the next one.
-            line["parity_max_abs_mm_vs_host_oracle"] = (res[0][0].cpu() - ref[0][0]).abs().max().item()
-    if rank == 0 and world == 1 and args.config == "cfg3":
-        # frame 0 of this workload is fixture case `cfg3` of tests/golden/predictor.npz,
-        # i.e. the output of the imported upstream reference on the same input
+            line["parity_max_abs_mm_vs_host_oracle"] = (res[0][0][0].cpu() - ref[0][0]).abs().max().item()
+    if rank == 0 and world == 1 and size == "small" and args.config in ("cfg3", "cfg2", "cfg5"):
+        # frame 0 of this workload is a fixture case of tests/golden/predictor.npz, i.e. the
+        # output of the imported upstream reference on the same input
         import numpy as np
         gpath = os.path.join(ROOT, "tests", "golden", "predictor.npz")
-        if os.path.isfile(gpath):
+        if os.path.isfile(gpath) and args.config == "cfg3":
             gold = np.load(gpath)["cfg3.points3D"]
             line["parity_max_abs_mm_vs_reference_fixture"] = float(
-                np.abs(res[0][0].cpu().numpy() - gold[0]).max())
+                np.abs(res[0][0][0].cpu().numpy() - gold[0]).max())
 
-    if sharded and (world > 1 or os.environ.get("JH_BENCH_REPLICAS")):
-        # next to the camera-sharded number, the frame-parallel upper bound --
-        # every rank runs the whole path on its own `--time-batch` frames, no data-path
-        # collective (what a throughput-only deployment would do)
+    if rank == 0 and not sharded and not args.no_secondary and size == "small" and args.config == "cfg3":
+        # ---- SURVEY 8d secondary line: the `medium` models (config.py's default size) on the
+        # same workload, same method, fewer steps
         try:
-            del sh, pred, fr, shs, preds
-            torch.cuda.empty_cache()
-            from jarvis_hybridnet_amd._predictor import MultiStreamPredictor
-            Tb, Kr = 32, max(1, args.streams)
-            rp = MultiStreamPredictor(lambda: NativePredictor(sd_c, sd_h, **dict(common, time_batch=Tb)),
-                                      streams=Kr)
-            rp.set_calibration(*[t.to(dev) for t in calib])
-            T_keep, T = T, Tb
-            rfr = device_frames(0, c["C"])
-            T = T_keep
-            routs = [(torch.empty((Tb, c["J"], 3), device=dev), torch.empty((Tb, c["J"]), device=dev),
-                      torch.empty((Tb,), device=dev, dtype=torch.int32)) for _ in range(Kr)]
+            Tm = min(T, 16)
+            sd_cm = S.efficienttrack_weights("medium", 1, 50)
+            sd_hm = S.hybridnet_weights("medium", c["J"], 51)
+            mm = MultiStreamPredictor(lambda: NativePredictor(sd_cm, sd_hm, **common_kw("medium", Tm)),
+                                      streams=K)
+            mm.set_calibration(*calib_dev)
+            frm = device_frames(0, c["C"], Tm)
+            for _ in range(2 * K):
+                mm.forward(frm)
             torch.cuda.synchronize()
-            for _ in range(max(1, args.warmup)):
-                for i in range(Kr):
-                    rp.forward(rfr, routs[i])
-            barrier()
+            nst = max(2, args.steps // 2)
             t0 = time.perf_counter()
-            for _ in range(args.steps):
-                for i in range(Kr):
-                    rp.forward(rfr, routs[i])
-            barrier()
-            tt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            line["replicas_only"] = {"value": Tb * Kr * world * args.steps / tt.item(),
-                                     "unit": "multi-view frames/s",
-                                     "note": "frame-parallel upper bound: each rank runs all %d cameras "
-                                             "of its own frames (%d streams x %d frames per step), no "
-                                             "collective" % (c["C"], Kr, Tb)}
-        except Exception as e:                      # never lose the headline number to the extra
-            line["replicas_only"] = {"error": repr(e)[:200]}
+            for _ in range(nst * K):
+                mm.forward(frm)
+            torch.cuda.synchronize()
+            mdt = time.perf_counter() - t0
+            line["secondary"] = {"workload": c["workload"].replace("small/small", "medium/medium"),
+                                 "value": Tm * K * nst / mdt, "unit": "multi-view frames/s",
+                                 "ms_per_step": 1e3 * mdt / nst, "time_batch": Tm, "streams": K, "steps": nst}
+            del mm, frm
+        except Exception as e:                      # the secondary line never costs the headline
+            line["secondary"] = {"error": repr(e)[:200]}
+
+    if sharded and (world > 1 or os.environ.get("JH_BENCH_SIDE_LEGS")) and not args.no_side_legs:
+        line.update(side_legs(args, c, common, sd_c, sd_h, calib_dev, device_frames, dev, dist, world, T, gs,
+                              make_sharded if args.three_d == "sharded" else None, fr, barrier))
     if sharded:
         dist.destroy_process_group()
     if rank == 0:
         sys.stdout.flush()
         print(json.dumps(line), flush=True)       # the ONE JSON line, last thing on stdout
+
+
+def side_legs(args, c, common, sd_c, sd_h, calib_dev, device_frames, dev, dist, world, T, gs, make_sharded, fr,
+              barrier):
+    """Multi-GPU side measurements next to the camera-sharded `value`: (1) the
+    literal north-star placement -- heatmaps all-gathered, 3D stage on rank 0 -- and (2) the
+    frame-parallel upper bound `replicas_only`.  Failure-safe: set-up happens under try on
+    every rank, then ONE unconditional all_reduce tells every rank whether all are ready, so no
+    rank is ever left alone inside a collective; a failed leg reports an error string."""
+    from jarvis_hybridnet_amd._predictor import MultiStreamPredictor, NativePredictor
+    out = {}
+
+    def all_ok(ok):
+        flag = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
+
+    # ---- (1) 3D stage on rank 0 of each group (unpipelined: rank 0's V2V is the critical path)
+    if make_sharded is not None:
+        sh0, err = None, None
+        try:
+            _, ss = make_sharded("rank0", 1)
+            sh0 = ss[0]
+        except Exception as e:
+            err = repr(e)[:200]
+        if all_ok(sh0 is not None):
+            for _ in range(2):
+                sh0.step(fr)
+            barrier()
+            t0 = time.perf_counter()
+            nst = max(2, args.steps // 2)
+            for _ in range(nst):
+                sh0.step(fr)
+            barrier()
+            tt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            out["three_d_rank0"] = {"value": T * (world // gs) * nst / tt.item(), "unit": "multi-view frames/s",
+                                    "note": "BASELINE configs[3] placement: RCCL all-gather of heatmaps, "
+                                            "reprojection + V2V + soft-argmax of all %d frames on rank 0 of "
+                                            "each group (Amdahl-bound by construction)" % T}
+        else:
+            out["three_d_rank0"] = {"error": err or "set-up failed on another rank"}
+        del sh0
+        torch.cuda.empty_cache()
+
+    # ---- (2) frame-parallel upper bound: every rank runs the whole path on its own frames
+    rp, err, Tb, Kr = None, None, args.time_batch, max(1, args.streams)
+    try:
+        rp = MultiStreamPredictor(lambda: NativePredictor(sd_c, sd_h, **dict(common, time_batch=Tb)), streams=Kr)
+        rp.set_calibration(*calib_dev)
+        rfr = device_frames(0, c["C"], Tb)
+        for _ in range(2 * Kr):
+            rp.forward(rfr)
+        torch.cuda.synchronize()
+    except Exception as e:
+        err, rp = repr(e)[:200], None
+    if all_ok(rp is not None):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps * Kr):
+            rp.forward(rfr)
+        barrier()
+        tt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        out["replicas_only"] = {"value": Tb * Kr * world * args.steps / tt.item(), "unit": "multi-view frames/s",
+                                "note": "frame-parallel upper bound: each rank runs all %d cameras of its own "
+                                        "frames (%d streams x %d frames per step), no collective" % (
+                                            c["C"], Kr, Tb)}
+    else:
+        out["replicas_only"] = {"error": err or "set-up failed on another rank"}
+    return out
 
 
 if __name__ == "__main__":

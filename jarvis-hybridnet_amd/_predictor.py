@@ -130,7 +130,8 @@ class MultiStreamPredictor:
     synchronize() (or wait on `last_event`) before reading them.
     """
 
-    def __init__(self, make_predictor, streams=3):
+    def __init__(self, make_predictor, streams=3, timing=False):
+        self.timing = timing                         # events usable with elapsed_time (bench.py)
         self.preds = [make_predictor() for _ in range(streams)]
         self.streams = [torch.cuda.Stream() for _ in range(streams)]
         self.events = [None] * streams
@@ -168,7 +169,7 @@ class MultiStreamPredictor:
             t.record_stream(s)
         with torch.cuda.stream(s):
             res = self.preds[i].forward(frames, out)
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(enable_timing=self.timing)
             ev.record(s)
         self.events[i] = ev
         self.last_event = ev
