@@ -15,11 +15,16 @@ struct WinoArgs {
   int in_act;
   double* stats;           // [N][cout_p][2] or nullptr
   int N, D, H, W, cin_p, cout_p, cout_p16;
+  int abl;                 // experiment knob (JH_WS_ABL), 0 in production
+  long long* dbg;          // per-phase cycle sums of workgroup 0 (JH_WINO_DBG), nullptr in production
 };
 
 constexpr int kWTY = 8, kWTX = 8;                           // (y, x) outputs per workgroup
 constexpr int kWPY = kWTY + 2, kWPX = kWTX + 2;
 
 int launch_conv3d_wino_pp(const WinoArgs& a, int nr, hipStream_t s);
+int launch_conv3d_wino_ws(const WinoArgs& a, int nr, hipStream_t s);
+// persistent form; returns -1 when the launch should fall back to the one-role kernel
+int launch_conv3d_wino_pw(const WinoArgs& a, int nr, hipStream_t s);
 
 }  // namespace jh

@@ -364,11 +364,17 @@ int pack_wino_weights(int cin, int cout, const float* w, const float* b, ConvWei
   return 0;
 }
 
-// variant: 0 = 4 z-slices per workgroup (default), 1 = 2 z-slices, 2 = two-wave-set form
+// variant: 4 = persistent wave-specialised form (conv3d_wino_pw.hip; the default -- it falls
+// back to variant 0 for launches with fewer than two tiles per CU or fewer than three channel
+// passes), 0 = one role per workgroup, 4 z-slices (JH_WINO_PW=0), 1 = the same with 2 z-slices
+// (JH_WINO_TZ=2), 2 = two-wave-set form (JH_WINO_PP=1), 3 = wave-specialised, one tile per
+// workgroup (JH_WINO_WS=1)
 int wino_variant_from_env() {
+  if (const char* e = getenv("JH_WINO_WS")) { if (atoi(e) != 0) return 3; }
   if (const char* e = getenv("JH_WINO_PP")) { if (atoi(e) != 0) return 2; }
   if (const char* e = getenv("JH_WINO_TZ")) { if (atoi(e) == 2) return 1; }
-  return 0;
+  if (const char* e = getenv("JH_WINO_PW")) { if (atoi(e) == 0) return 0; }
+  return 4;
 }
 
 int launch_conv3d_wino(const ConvWeights& w, const Act& x, const Act& y, double* stats, hipStream_t s,
@@ -386,6 +392,11 @@ int launch_conv3d_wino(const ConvWeights& w, const Act& x, const Act& y, double*
   // batches share the GPU (137 KB of LDS and 8 waves per CU), so both stay opt-in.
   const int tz = variant == 1 ? 2 : 4;
   if (variant == 2) return launch_conv3d_wino_pp(a, nr, s);
+  if (variant == 3) return launch_conv3d_wino_ws(a, nr, s);
+  if (variant == 4) {
+    const int rc = launch_conv3d_wino_pw(a, nr, s);
+    if (rc >= 0) return rc;                 // -1: too few tiles / one channel pass -> one-role kernel
+  }
   const int blocks = ((x.D + tz - 1) / tz) * ((x.H + kWTY - 1) / kWTY) * ((x.W + kWTX - 1) / kWTX);
   dim3 grid(blocks, (nb + nr - 1) / nr, x.N);
   const size_t xbytes = (size_t)4 * 2 * tz * nr * 4 * 64 * sizeof(float);

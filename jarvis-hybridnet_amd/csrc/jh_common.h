@@ -194,7 +194,7 @@ int launch_bifpn_node(const NodeArgs& a, hipStream_t s);
 int pack_wino_weights(int cin, int cout, const float* w, const float* b, ConvWeights* out);
 int wino_variant_from_env();
 int launch_conv3d_wino(const ConvWeights& w, const Act& x, const Act& y, double* stats, hipStream_t s,
-                       const InNorm* in, int variant = 0);
+                       const InNorm* in, int variant = 4);
 int launch_deconv_c1(const Act& x, const double* stats, float inv_cnt, int in_act, const float* w,
                      const Act& y, hipStream_t s);
 

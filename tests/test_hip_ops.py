@@ -113,6 +113,16 @@ def test_conv3d_winograd_equals_direct(cin, cout, D, H, W, monkeypatch):
     monkeypatch.setenv("JH_WINO_PP", "1")          # the two-wave-set ("ping-pong") form
     y_p, _ = _conv(3, 0, 3, 1, 1, cin, cout, x, w, b, norm_act=1)
     monkeypatch.delenv("JH_WINO_PP")
+    monkeypatch.setenv("JH_WINO_WS", "1")          # the wave-specialised form
+    y_s, _ = _conv(3, 0, 3, 1, 1, cin, cout, x, w, b, norm_act=1)
+    monkeypatch.delenv("JH_WINO_WS")
+    es = rel_err(y_s, ref)
+    report("conv3d_winograd_ws", cin=cin, cout=cout, rel=es)
+    assert es < 2e-4
+    monkeypatch.setenv("JH_WINO_PW", "0")          # the one-role kernel (default: persistent form,
+    y_q, _ = _conv(3, 0, 3, 1, 1, cin, cout, x, w, b, norm_act=1)   # which falls back to it here)
+    monkeypatch.delenv("JH_WINO_PW")
+    assert rel_err(y_q, ref) < 2e-4
     monkeypatch.setenv("JH_WINO", "0")
     y_d, _ = _conv(3, 0, 3, 1, 1, cin, cout, x, w, b, norm_act=1)
     ew, ep, ed = rel_err(y_w, ref), rel_err(y_p, ref), rel_err(y_d, ref)
@@ -149,3 +159,22 @@ def test_depthwise(k, c, H, W, norm_act):
     e = rel_err(y, ref)
     report("depthwise", k=k, c=c, rel=e)
     assert e < 2e-5 * (10 if norm_act >= 0 else 1)
+
+
+@pytest.mark.parametrize("cin,cout,N,G,in_norm", [(46, 46, 5, 32, 1), (92, 92, 20, 16, 0), (60, 60, 3, 48, 1)])
+def test_conv3d_winograd_persistent(cin, cout, N, G, in_norm, monkeypatch):
+    """The persistent wave-specialised Winograd kernel (csrc/conv3d_wino_pw.hip, the default for
+    launches with at least two tiles per CU) against torch, on the V2V layer shapes: 46->46 @ 32^3
+    and 92->92 @ 16^3 (J = 23), 60->60 @ 48^3 (J = 30: two column-block groups).  Odd image counts
+    give the workgroups unequal tile lists."""
+    g = torch.Generator().manual_seed(cin + N)
+    x = torch.randn(N, cin, G, G, G, generator=g)
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) / (cin * 27) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    y, ref = _conv(3, 0, 3, 1, 1, cin, cout, x, w, b, norm_act=1 if in_norm else -1)
+    monkeypatch.setenv("JH_WINO_PW", "0")
+    y0, _ = _conv(3, 0, 3, 1, 1, cin, cout, x, w, b, norm_act=1 if in_norm else -1)
+    e, e0 = rel_err(y, ref), rel_err(y0, ref)
+    report("conv3d_winograd_persistent", cin=cin, cout=cout, n=N, g=G, rel=e, rel_one_role=e0)
+    assert e < 2e-4 and e0 < 2e-4
+    assert not torch.equal(y, y0), "the persistent kernel did not run"

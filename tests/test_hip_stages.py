@@ -201,3 +201,31 @@ def test_submodule_path_graph_capture(golden):
         assert torch.equal(a, b) or (a - b).abs().max().item() <= 1e-5 * a.abs().max().item()
     g = golden("geometry")
     assert (captured[1].cpu() - torch.from_numpy(g["c4.reconstruct"])).abs().max() < 1e-3
+
+
+def test_v2v_time_batch_runs_persistent_kernel(monkeypatch):
+    """V2VNet on a time batch of 5 volumes (64^3, J = 23): 640 output tiles per Res3DBlock conv,
+    which is where the persistent wave-specialised Winograd kernel (csrc/conv3d_wino_pw.hip) takes
+    over from the one-role kernel (T = 1 falls back to it).  Covers its InstanceNorm(+ReLU)-on-load
+    commit path, the fused statistics and unequal per-workgroup tile lists, against the oracle."""
+    from jarvis_hybridnet_amd import synthetic as S
+    from jarvis_hybridnet_amd.hybridnet.v2vnet import V2VNet
+    from oracle import hybridnet_oracle as O
+    J, G, T = 23, 64, 5
+    sd = S.v2v_weights(J, 22)
+    x = torch.cat([cases.v2v_input(J, G, 30 + t) for t in range(T)])
+    with torch.no_grad():
+        ref = torch.cat([O.v2v_forward(sd, x[t:t + 1]) for t in range(T)])
+    net = V2VNet(J, J)
+    net.load_state_dict(sd, strict=True)
+    out = net(cuda(x))
+    torch.cuda.synchronize()
+    monkeypatch.setenv("JH_WINO_PW", "0")                   # the one-role kernel on the same batch
+    net0 = V2VNet(J, J)
+    net0.load_state_dict(sd, strict=True)
+    out0 = net0(cuda(x))
+    torch.cuda.synchronize()
+    e, e0 = rel_err(out, ref), rel_err(out0, ref)
+    report("v2v_time_batch", rel_persistent=e, rel_one_role=e0)
+    assert e < 1e-3 and e0 < 1e-3
+    assert not torch.equal(out, out0), "the persistent kernel did not run"
