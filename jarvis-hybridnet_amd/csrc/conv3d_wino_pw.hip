@@ -23,13 +23,21 @@
 // kernel -- run under MFMAs; the matrix cores wait only for the two dump hand-overs per tile.
 //
 // Barriers per tile (all 8 waves; `wg_barrier` waits for LDS traffic only, so global loads in
-// flight stay in flight): two per channel pass, three for the dump.
-//   matrix : [fx 0,1 | Bm | fx 2,3 | Be] x P   dump(ox 0) Bd1      Bd2 dump(ox 1) Bd3
-//   staging: [finish tile-1, commit g+1 | Bm | atomics tile-1, transform g+1, request g+2 | Be] x P
-//                                               Bd1 read(ox 0) Bd2                  Bd3 read(ox 1)
-// LDS: R [600][8] 19 KB, V [2][6][16][16][8] 98 KB (XOR-swizzled channel quads: an A operand's
-// 16 tile rows x 4 k-quads hit 64 distinct banks), statistics scratch 1.5 KB; the dump uses the
-// V buffer of the pass just consumed (49 KB for NR = 3).
+// flight stay in flight): one per channel pass, four for the dump hand-over.  With g = global
+// pass index (tile k, pass p):
+//   matrix    : [MFMAs of pass g from V[g & 1] | Be] x P   dump(ox 0) Bd1 . Bd2 dump(ox 1) Bd3 . Bd4
+//   loader    : [commit pass g+2 -> R[g & 1], request pass g+3          | Be] x P
+//   transform : [R[(g+1) & 1] -> V[(g+1) & 1]                           | Be] x P
+//   all staging waves: in pass 0 the ox = 1 half of the previous tile's epilogue, then its
+//               statistics atomics;  at the tile end Bd1 read(ox 0) Bd2 finish(ox 0) Bd3 read(ox 1) Bd4
+// Measured (JH_WINO_DBG cycle counters, 46 -> 46 @ 32^3): while a matrix wave streams fp32 MFMAs
+// the staging wave of the same SIMD issues about one instruction per MFMA slot (45-50 cycles),
+// whatever its type or priority -- so the staging instruction COUNT per pass is budgeted against
+// the 288 MFMAs of a pass: buffer loads with scalar offsets and out-of-range zero padding (no
+// address or mask arithmetic), packed fp32 math, mode dispatch outside the item loops.
+// LDS: R [2][608][8] 39 KB, V [2][6][16][16][8] 98 KB (XOR-swizzled channel quads: an A
+// operand's 16 tile rows x 4 k-quads hit 64 distinct banks), statistics scratch, mean / rstd
+// table: 139 KB; the dump uses the V buffer of the pass just consumed (49 KB for NR = 3).
 #include <cstdlib>
 #include <type_traits>
 #include "conv_mfma.h"
@@ -417,6 +425,8 @@ __global__ __launch_bounds__(512) void conv3d_wino_pw_kernel(const WinoArgs a, i
         if (ABL != 1) finish_half(cur, 0);
         wg_barrier();                                       // Bd3: dump(ox 1) complete
         read_dump(D);
+        wg_barrier();                                       // Bd4: every staging wave has read it (the
+                                                            // transform waves overwrite D in the next pass)
         prev = cur; cur = nxt;
         JH_T(6);
       }
@@ -552,6 +562,7 @@ __global__ __launch_bounds__(512) void conv3d_wino_pw_kernel(const WinoArgs a, i
 #pragma unroll
         for (int nr = 0; nr < NR; ++nr) acc[fi][mr][nr] = (f32x4){0.f, 0.f, 0.f, 0.f};
     wg_barrier();                                           // Bd3
+    wg_barrier();                                           // Bd4
     JH_T(3);
     if (has_next && nxt.nb0 != cur.nb0) {                   // other column-block group: the weights
       set_group(nxt.nb0);                                   // requested ahead were the wrong ones
