@@ -62,7 +62,7 @@ static size_t carve_reproject(Carver& c, int cams, int joints, int hs, int g, Re
 struct SoftWs { Act x; double* partial; int* pmax; };
 static size_t carve_softargmax(Carver& c, int t, int joints, int gh, SoftWs* w) {
   c.act(t, gh, gh, gh, joints, &w->x);
-  w->partial = c.take<double>((size_t)t * w->x.Cp * 4);
+  w->partial = c.take<double>((size_t)t * w->x.Cp * 4 * kLimbs);
   w->pmax = c.take<int>((size_t)t * w->x.Cp);
   return c.off;
 }
@@ -316,7 +316,7 @@ int jh_predictor_create(const jh_params* center_params, const jh_params* hybrid_
   if (m.get(reinterpret_cast<void**>(&pr->valid), (size_t)T * sizeof(int))) return 1;
   if (m.get(reinterpret_cast<void**>(&pr->coarse),
             (size_t)pr->T3 * C * pr->Gh * pr->Gh * pr->Gh * sizeof(float2))) return 1;
-  if (m.get(reinterpret_cast<void**>(&pr->sa_partial), (size_t)T * pr->Jp * 4 * sizeof(double))) return 1;
+  if (m.get(reinterpret_cast<void**>(&pr->sa_partial), (size_t)T * pr->Jp * 4 * kLimbs * sizeof(double))) return 1;
   if (m.get(reinterpret_cast<void**>(&pr->sa_max), (size_t)T * pr->Jp * sizeof(int))) return 1;
   JH_CHECK_HIP(hipMemset(pr->valid, 0, (size_t)T * sizeof(int)));
   JH_CHECK_HIP(hipDeviceSynchronize());
@@ -594,8 +594,8 @@ int jh_op_conv(int nd, int kind, int k, int stride, int pad, int cin, int cout,
   int rc = 0;
   do {
     if (norm_act >= 0) {
-      if ((rc = sc.get(reinterpret_cast<void**>(&stats), (size_t)n * y.Cp * 2 * sizeof(double)))) break;
-      if (hipMemsetAsync(stats, 0, (size_t)n * y.Cp * 2 * sizeof(double), s) != hipSuccess) { rc = 1; break; }
+      if ((rc = sc.get(reinterpret_cast<void**>(&stats), (size_t)n * y.Cp * kStatW * sizeof(double)))) break;
+      if (hipMemsetAsync(stats, 0, (size_t)n * y.Cp * kStatW * sizeof(double), s) != hipSuccess) { rc = 1; break; }
     }
     if (gate_dev) {   // (N,Cin) -> padded (N,Cin_p)
       if ((rc = sc.get(reinterpret_cast<void**>(&gate_p), (size_t)n * x.Cp * sizeof(float)))) break;
@@ -628,8 +628,8 @@ int jh_op_depthwise(int k, int c, const float* w_host, const float* x_dev, int n
   if (sc.get(reinterpret_cast<void**>(&wd), wt.size() * sizeof(float))) return 1;
   JH_CHECK_HIP(hipMemcpyAsync(wd, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice, s));
   if (norm_act >= 0) {
-    if (sc.get(reinterpret_cast<void**>(&stats), (size_t)n * x.Cp * 2 * sizeof(double))) return 1;
-    JH_CHECK_HIP(hipMemsetAsync(stats, 0, (size_t)n * x.Cp * 2 * sizeof(double), s));
+    if (sc.get(reinterpret_cast<void**>(&stats), (size_t)n * x.Cp * kStatW * sizeof(double))) return 1;
+    JH_CHECK_HIP(hipMemsetAsync(stats, 0, (size_t)n * x.Cp * kStatW * sizeof(double), s));
   }
   if (launch_to_channel_last(x_dev, x, s)) return 1;
   if (launch_depthwise(x, wd, k, y.p, stats, s)) return 1;

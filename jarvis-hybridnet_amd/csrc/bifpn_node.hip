@@ -94,9 +94,9 @@ __global__ __launch_bounds__(512, 6) void bifpn_node_kernel(const NodeArgs a) {
     bool has_st = false;
     const int sk = tid / Cp, scn = tid - sk * Cp;        // launcher: n_in * Cp <= 512
     if (tid < a.n_in * Cp && a.st[sk]) {
-      const double* st = a.st[sk] + ((size_t)n * Cp + scn) * 2;
-      sv0 = st[0];
-      sv1 = st[1];
+      const double* st = a.st[sk] + ((size_t)n * Cp + scn) * kStatW;
+      sv0 = exact_read(st);
+      sv1 = exact_read(st + kLimbs);
       has_st = true;
     }
     float dwv[2];                                        // launcher: 9 * Cp <= 1024
@@ -235,9 +235,9 @@ __global__ __launch_bounds__(512, 6) void bifpn_node_kernel(const NodeArgs a) {
       const int k = i / Cp, c = i % Cp;
       float mean = 0.f, rstd = 1.f;
       if (a.st[k]) {
-        const double* st = a.st[k] + ((size_t)n * Cp + c) * 2;
-        const double mu = st[0] * (double)a.inv_cnt[k];
-        double var = st[1] * (double)a.inv_cnt[k] - mu * mu;
+        const double* st = a.st[k] + ((size_t)n * Cp + c) * kStatW;
+        const double mu = exact_read(st) * (double)a.inv_cnt[k];
+        double var = exact_read(st + kLimbs) * (double)a.inv_cnt[k] - mu * mu;
         if (var < 0.0) var = 0.0;
         mean = (float)mu;
         rstd = (float)(1.0 / sqrt(var + 1e-5));
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(512, 6) void bifpn_node_kernel(const NodeArgs a) {
   EpilogueArgs e;
   e.y = a.y + (size_t)n * a.H * a.W * a.cout_p;
   e.bias = a.bias;
-  e.stats = a.stats ? a.stats + (size_t)n * a.cout_p * 2 : nullptr;
+  e.stats = a.stats ? a.stats + (size_t)n * a.cout_p * kStatW : nullptr;
   e.Dout = 1; e.Hout = a.H; e.Wout = a.W; e.Hy = a.H; e.Wy = a.W;
   e.cout_p = a.cout_p; e.cout_p16 = a.cout_p16; e.os = 1; e.osz = 1; e.offz = e.offy = e.offx = 0;
   for (int nb0 = 0; nb0 < nb; nb0 += kNodeNRG) {

@@ -1,5 +1,5 @@
-// Shared declarations of the two Winograd 3D convolution kernels (conv3d_wino.hip: one role per
-// workgroup; conv3d_wino_pp.hip: two wave sets alternating roles).
+// Shared declarations of the Winograd 3D convolution kernels (conv3d_wino.hip: one role per
+// workgroup, one tile each; conv3d_wino_pw.hip: persistent, wave-specialised).
 #pragma once
 #include "jh_common.h"
 
@@ -22,8 +22,6 @@ struct WinoArgs {
 constexpr int kWTY = 8, kWTX = 8;                           // (y, x) outputs per workgroup
 constexpr int kWPY = kWTY + 2, kWPX = kWTX + 2;
 
-int launch_conv3d_wino_pp(const WinoArgs& a, int nr, hipStream_t s);
-int launch_conv3d_wino_ws(const WinoArgs& a, int nr, hipStream_t s);
 // persistent form; returns -1 when the launch should fall back to the one-role kernel
 int launch_conv3d_wino_pw(const WinoArgs& a, int nr, hipStream_t s);
 

@@ -58,12 +58,15 @@ __global__ __launch_bounds__(256, (kWTZ == 2 ? 2 : 1)) void conv3d_wino_kernel(c
 
   if (a.in_stats) {
     for (int c = tid; c < a.cin_p; c += 256) {
-      const double* st = a.in_stats + ((size_t)n * a.cin_p + c) * 2;
-      const double mu = st[0] * (double)a.in_inv;
-      double var = st[1] * (double)a.in_inv - mu * mu;
+      const double* st = a.in_stats + ((size_t)n * a.cin_p + c) * kStatW;
+      const double mu = exact_read(st) * (double)a.in_inv;
+      double var = exact_read(st + kLimbs) * (double)a.in_inv - mu * mu;
       if (var < 0.0) var = 0.0;
-      nrm[c] = (float)mu;
-      nrm[a.cin_p + c] = (float)(1.0 / sqrt(var + 1e-5));
+      // (mean is stored as -mean * rstd: the commit is one FMA, exactly as in conv3d_wino_pw.hip --
+      // the two kernels must agree bit for bit, a launch picks one or the other by its tile count)
+      const float rsf = (float)(1.0 / sqrt(var + 1e-5));
+      nrm[c] = -(float)mu * rsf;
+      nrm[a.cin_p + c] = rsf;
     }
   }
   const float* __restrict__ xin = a.x + (size_t)n * a.D * a.H * a.W * a.cin_p;
@@ -121,10 +124,10 @@ __global__ __launch_bounds__(256, (kWTZ == 2 ? 2 : 1)) void conv3d_wino_kernel(c
         float4 v = pf[it];
         if ((okmask >> it & 1) && a.in_stats) {
           const int c = c0 + (idx & 1) * 4;
-          const float4 mu = *reinterpret_cast<const float4*>(nrm + c);
+          const float4 nm = *reinterpret_cast<const float4*>(nrm + c);
           const float4 rs = *reinterpret_cast<const float4*>(nrm + a.cin_p + c);
-          v.x = (v.x - mu.x) * rs.x; v.y = (v.y - mu.y) * rs.y;
-          v.z = (v.z - mu.z) * rs.z; v.w = (v.w - mu.w) * rs.w;
+          v.x = fmaf(v.x, rs.x, nm.x); v.y = fmaf(v.y, rs.y, nm.y);
+          v.z = fmaf(v.z, rs.z, nm.z); v.w = fmaf(v.w, rs.w, nm.w);
           if (a.in_act == ACT_RELU) {
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
           } else if (a.in_act == ACT_SILU) {
@@ -188,20 +191,20 @@ __global__ __launch_bounds__(256, (kWTZ == 2 ? 2 : 1)) void conv3d_wino_kernel(c
 #pragma unroll
         for (int nr = 0; nr < NR; ++nr)
           bv[dz][nr] = fi == 0 ? b0v[dz][nr] : U2[(size_t)(((f * 3 + dz) * nk8 + kk) * nb) * 64 + boff[nr]];
+      // (z tap outermost, like the persistent kernel: the same accumulation order per output)
 #pragma unroll
-      for (int dz = 0; dz < 3; ++dz)
+      for (int dz = 0; dz < 3; ++dz) {
 #pragma unroll
         for (int mr = 0; mr < kWTZ; ++mr)
 #pragma unroll
           for (int nr = 0; nr < NR; ++nr)
             acc[fi][mr][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mr + dz].x, bv[dz][nr].x, acc[fi][mr][nr], 0, 0, 0);
 #pragma unroll
-      for (int dz = 0; dz < 3; ++dz)
-#pragma unroll
         for (int mr = 0; mr < kWTZ; ++mr)
 #pragma unroll
           for (int nr = 0; nr < NR; ++nr)
             acc[fi][mr][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mr + dz].y, bv[dz][nr].y, acc[fi][mr][nr], 0, 0, 0);
+      }
     }
   }
 
@@ -300,9 +303,7 @@ __global__ __launch_bounds__(256, (kWTZ == 2 ? 2 : 1)) void conv3d_wino_kernel(c
           t1 += X[(w * NR * 16 + tid) * 2 + 0];
           t2 += X[(w * NR * 16 + tid) * 2 + 1];
         }
-        double* st = a.stats + ((size_t)n * a.cout_p + ch) * 2;
-        unsafeAtomicAdd(st + 0, (double)t1);
-        unsafeAtomicAdd(st + 1, (double)t2);
+        stat_add(a.stats + ((size_t)n * a.cout_p + ch) * kStatW, t1, t2);
       }
     }
   }
@@ -367,11 +368,8 @@ int pack_wino_weights(int cin, int cout, const float* w, const float* b, ConvWei
 // variant: 4 = persistent wave-specialised form (conv3d_wino_pw.hip; the default -- it falls
 // back to variant 0 for launches with fewer than two tiles per CU or fewer than three channel
 // passes), 0 = one role per workgroup, 4 z-slices (JH_WINO_PW=0), 1 = the same with 2 z-slices
-// (JH_WINO_TZ=2), 2 = two-wave-set form (JH_WINO_PP=1), 3 = wave-specialised, one tile per
-// workgroup (JH_WINO_WS=1)
+// (JH_WINO_TZ=2)
 int wino_variant_from_env() {
-  if (const char* e = getenv("JH_WINO_WS")) { if (atoi(e) != 0) return 3; }
-  if (const char* e = getenv("JH_WINO_PP")) { if (atoi(e) != 0) return 2; }
   if (const char* e = getenv("JH_WINO_TZ")) { if (atoi(e) == 2) return 1; }
   if (const char* e = getenv("JH_WINO_PW")) { if (atoi(e) == 0) return 0; }
   return 4;
@@ -386,13 +384,9 @@ int launch_conv3d_wino(const ConvWeights& w, const Act& x, const Act& y, double*
   a.N = x.N; a.D = x.D; a.H = x.H; a.W = x.W; a.cin_p = x.Cp; a.cout_p = y.Cp; a.cout_p16 = w.cout_p16;
   const int nb = w.cout_p16 / 16;
   const int nr = (nb % 3 == 0) ? 3 : ((nb % 2 == 0) ? 2 : (nb == 1 ? 1 : 3));
-  // measured (46->46 @ 32^3, 8 volumes): 4 z-slices 0.184 ms, 2 z-slices 0.188 ms -- the second
-  // resident workgroup does not pay for the doubled per-workgroup prologue / epilogue.  The
-  // two-wave-set form (conv3d_wino_pp.hip) is 0.176 ms alone but gains nothing once three time
-  // batches share the GPU (137 KB of LDS and 8 waves per CU), so both stay opt-in.
+  // (2 z-slices per workgroup measure the same as 4: the second resident workgroup only pays for
+  // the doubled per-workgroup prologue / epilogue; kept as an experiment knob)
   const int tz = variant == 1 ? 2 : 4;
-  if (variant == 2) return launch_conv3d_wino_pp(a, nr, s);
-  if (variant == 3) return launch_conv3d_wino_ws(a, nr, s);
   if (variant == 4) {
     const int rc = launch_conv3d_wino_pw(a, nr, s);
     if (rc >= 0) return rc;                 // -1: too few tiles / one channel pass -> one-role kernel

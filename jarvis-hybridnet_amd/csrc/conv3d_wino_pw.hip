@@ -166,9 +166,9 @@ __global__ __launch_bounds__(512) void conv3d_wino_pw_kernel(const WinoArgs a, i
     auto norm_table = [&](int n) __attribute__((always_inline)) {
       if (a.in_stats) {
         for (int c = lane; c < a.cin_p; c += 64) {
-          const double2 st = reinterpret_cast<const double2*>(a.in_stats)[(size_t)n * a.cin_p + c];
-          const double m = st.x * (double)a.in_inv;
-          double var = st.y * (double)a.in_inv - m * m;
+          const double* st = a.in_stats + ((size_t)n * a.cin_p + c) * kStatW;
+          const double m = exact_read(st) * (double)a.in_inv;
+          double var = exact_read(st + kLimbs) * (double)a.in_inv - m * m;
           if (var < 0.0) var = 0.0;
           NT[c] = (float)m;
           NT[a.cin_p + c] = (float)(1.0 / sqrt(var + 1e-5));
@@ -341,9 +341,7 @@ __global__ __launch_bounds__(512) void conv3d_wino_pw_kernel(const WinoArgs a, i
             t1 += S[(w * NR * 16 + ht) * 2 + 0];
             t2 += S[(w * NR * 16 + ht) * 2 + 1];
           }
-          double* st = a.stats + ((size_t)t.n * a.cout_p + ch) * 2;
-          unsafeAtomicAdd(st + 0, (double)t1);
-          unsafeAtomicAdd(st + 1, (double)t2);
+          stat_add(a.stats + ((size_t)t.n * a.cout_p + ch) * kStatW, t1, t2);
         }
       }
     };

@@ -161,12 +161,15 @@ int launch_conv(const ConvDesc& d, const ConvWeights& w, const Act& x, const Act
     if (d.k == 5 && d.stride <= 2) return conv_launch_2d_k5(a, d.stride, nr, small, budget, s);
   } else {
     // small tile when the volume would otherwise give fewer blocks than CUs
+    // The choice depends on the IMAGE only, never on the batch size: fused statistics are sums of
+    // per-workgroup fp32 partials, so the tiling is part of the arithmetic, and a frame must give
+    // the same bits alone and inside any time batch (tests: test_forward_is_bitwise_reproducible).
     const long tiles_big = (long)((a.Dout + 1) / 2) * ((a.Hout + 3) / 4) * ((a.Wout + 15) / 16) *
-                           a.N * a.nphase * ((w.cout_p16 / 16 + nr - 1) / nr);
-    int small = tiles_big < 512 ? 1 : 0;
+                           a.nphase * ((w.cout_p16 / 16 + nr - 1) / nr);
+    int small = tiles_big < 16 ? 1 : 0;
     // 256-voxel tiles (4 row blocks per wave: half the weight traffic per MFMA, 2.5x
-    // instead of 3.4x halo) once there are at least ~3 workgroups per CU of them
-    if (!small && d.k == 3 && d.stride == 1 && tiles_big / 2 >= 768) small = 2;
+    // instead of 3.4x halo) for volumes of at least 32^3 outputs
+    if (!small && d.k == 3 && d.stride == 1 && tiles_big >= 256) small = 2;
     if (JH_ENV_KNOB("JH_CONV3D_TILE") >= 0) { const int v = JH_ENV_KNOB("JH_CONV3D_TILE"); if (!small || v == 1) small = v; }
     if (d.k == 1 && d.stride == 1) return conv_launch_3d_k1(a, nr, small, budget, s);
     if (d.k == 2 && d.stride == 2) return conv_launch_3d_k2s2(a, nr, small, budget, s);

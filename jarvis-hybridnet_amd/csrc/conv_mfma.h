@@ -127,8 +127,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[MR][NR], const Epilog
           s1 += red[(w * NR * 16 + tid) * 2 + 0];
           s2 += red[(w * NR * 16 + tid) * 2 + 1];
         }
-        unsafeAtomicAdd(e.stats + (size_t)ch * 2 + 0, (double)s1);
-        unsafeAtomicAdd(e.stats + (size_t)ch * 2 + 1, (double)s2);
+        stat_add(e.stats + (size_t)ch * kStatW, s1, s2);
       }
     }
   }
@@ -187,9 +186,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   if (a.in_stats) {
     // InstanceNorm of the input from the producer's fused statistics (biased variance)
     for (int c = tid; c < a.cin_p; c += 256) {
-      const double* st = a.in_stats + ((size_t)n * a.cin_p + c) * 2;
-      const double mu = st[0] * (double)a.in_inv;
-      double var = st[1] * (double)a.in_inv - mu * mu;
+      const double* st = a.in_stats + ((size_t)n * a.cin_p + c) * kStatW;
+      const double mu = exact_read(st) * (double)a.in_inv;
+      double var = exact_read(st + kLimbs) * (double)a.in_inv - mu * mu;
       if (var < 0.0) var = 0.0;
       nrm[c] = (float)mu;
       nrm[a.cin_p + c] = (float)(1.0 / sqrt(var + 1e-5));
@@ -479,7 +478,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   EpilogueArgs e;
   e.y = a.y + (size_t)n * a.Dy * a.Hy * a.Wy * a.cout_p;
   e.bias = a.bias;
-  e.stats = a.stats ? a.stats + (size_t)n * a.cout_p * 2 : nullptr;
+  e.stats = a.stats ? a.stats + (size_t)n * a.cout_p * kStatW : nullptr;
   e.Dout = a.Dout; e.Hout = a.Hout; e.Wout = a.Wout; e.Hy = a.Hy; e.Wy = a.Wy;
   e.cout_p = a.cout_p; e.cout_p16 = a.cout_p16; e.os = a.ostride; e.osz = a.ostride;
   e.offz = a.phase[ph].ooff[0]; e.offy = a.phase[ph].ooff[1]; e.offx = a.phase[ph].ooff[2];

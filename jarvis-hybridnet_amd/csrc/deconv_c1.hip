@@ -41,9 +41,9 @@ __global__ __launch_bounds__(256) void deconv_c1_kernel(
   for (int c = tid; c < Cp; c += 256) {
     float mean = 0.f, rstd = 1.f;
     if (st) {
-      const double* s2 = st + ((size_t)n * Cp + c) * 2;
-      const double mu = s2[0] * (double)inv_cnt;
-      double var = s2[1] * (double)inv_cnt - mu * mu;
+      const double* s2 = st + ((size_t)n * Cp + c) * kStatW;
+      const double mu = exact_read(s2) * (double)inv_cnt;
+      double var = exact_read(s2 + kLimbs) * (double)inv_cnt - mu * mu;
       if (var < 0.0) var = 0.0;
       mean = (float)mu;
       rstd = (float)(1.0 / sqrt(var + 1e-5));

@@ -25,7 +25,8 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 }
 
 // Block-level reduction of per-thread float4 partials that belong to channel
-// quad (tid % q), followed by fp64 atomics.  `nvals` = 1 (sum) or 2 (sum, sumsq).
+// quad (tid % q), followed by order-independent fp64 accumulation (exact_add: kLimbs
+// doubles per value).  `nvals` = 1 (sum) or 2 (sum, sumsq); dst_stride = values per channel.
 __device__ __forceinline__ void block_channel_reduce(float4 s1, float4 s2, int nvals, int q,
                                                      int rows, int tid, bool active,
                                                      double* dst, int dst_stride, float* sm) {
@@ -41,7 +42,7 @@ __device__ __forceinline__ void block_channel_reduce(float4 s1, float4 s2, int n
     const int comp = i & 3, v = (i >> 2) % nvals, c4 = (i >> 2) / nvals;
     float acc = 0.f;
     for (int r = 0; r < rows; ++r) acc += sm[(((size_t)r * q + c4) * nvals + v) * 4 + comp];
-    unsafeAtomicAdd(dst + (size_t)(c4 * 4 + comp) * dst_stride + v, (double)acc);
+    exact_add(dst + ((size_t)(c4 * 4 + comp) * dst_stride + v) * kLimbs, (double)acc);
   }
 }
 
@@ -62,9 +63,9 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(
     float m[4], rs[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const double* st = stats + ((size_t)n * Cp + c4 * 4 + j) * 2;
-      const double mu = st[0] / (double)P;
-      double var = st[1] / (double)P - mu * mu;
+      const double* st = stats + ((size_t)n * Cp + c4 * 4 + j) * kStatW;
+      const double mu = exact_read(st) / (double)P;
+      double var = exact_read(st + kLimbs) / (double)P - mu * mu;
       if (var < 0.0) var = 0.0;
       m[j] = (float)mu;
       rs[j] = (float)(1.0 / sqrt(var + (double)eps));
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(
     }
   }
   if (pool)
-    block_channel_reduce(ps, ps, 1, q, rows, tid, active, pool + (size_t)n * Cp, 1, sm);
+    block_channel_reduce(ps, ps, 1, q, rows, tid, active, pool + (size_t)n * Cp * kLimbs, 1, sm);
 }
 
 int launch_norm_apply(const Act& x, const double* stats, float eps, int act, const float* r1,
@@ -106,9 +107,11 @@ int launch_norm_apply(const Act& x, const double* stats, float eps, int act, con
   const int q = x.Cp / 4;
   JH_REQUIRE(q >= 1 && q <= 256, "channel count out of range for norm_apply");
   const int rows = 256 / q;
-  // aim at >= 4 blocks per CU worth of work, 8..64 pixels per row-slot
+  // 8..64 pixels per row-slot, at most 64 blocks per image.  Chosen from the image size alone:
+  // the pooled sums are sums of per-block fp32 partials, so the blocking is part of the
+  // arithmetic and must not depend on the batch size.
   int iters = 8;
-  while ((long)x.N * ((P + rows * iters - 1) / (rows * iters)) > 8192 && iters < 64) iters *= 2;
+  while ((P + rows * iters - 1) / (rows * iters) > 64 && iters < 64) iters *= 2;
   const int ppb = rows * iters;
   dim3 grid((P + ppb - 1) / ppb, x.N);
   const size_t sm = pool ? (size_t)rows * q * 4 * sizeof(float) : 0;
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(256) void se_gate_kernel(
   float* hid = sm + C;
   const int n = blockIdx.x;
   for (int c = threadIdx.x; c < C; c += blockDim.x)
-    mean[c] = (float)(pool[(size_t)n * Cp + c] * (double)inv_hw);
+    mean[c] = (float)(exact_read(pool + ((size_t)n * Cp + c) * kLimbs) * (double)inv_hw);
   __syncthreads();
   for (int j = threadIdx.x; j < S; j += blockDim.x) {
     float acc = br[j];
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(256) void depthwise_lds_kernel(
       const int comp = i & 3, v = (i >> 2) & 1, cq = i >> 3;
       float acc = 0.f;
       for (int r = 0; r < 32; ++r) acc += sm[(((size_t)r * 8 + cq) * 2 + v) * 4 + comp];
-      unsafeAtomicAdd(stats + ((size_t)n * Cp + c0 + cq * 4 + comp) * 2 + v, (double)acc);
+      exact_add(stats + (((size_t)n * Cp + c0 + cq * 4 + comp) * 2 + v) * kLimbs, (double)acc);
     }
   }
 }

@@ -312,10 +312,10 @@ __global__ __launch_bounds__(64) void triangulate_kernel(
     int* __restrict__ center_hm, int* __restrict__ valid, int C, float sx2, float sy2, float wdiv,
     int hw, int W, int H) {
   __shared__ double ata[16];
+  __shared__ double contrib[64][17];            // per-camera terms of A^T A (summed in camera order)
   __shared__ float ctr[3];
   __shared__ int cnt;
   const int t = blockIdx.x, c = threadIdx.x;
-  if (c < 16) ata[c] = 0.0;
   if (c == 0) cnt = 0;
   __syncthreads();
   if (c < C) {
@@ -345,7 +345,13 @@ __global__ __launch_bounds__(64) void triangulate_kernel(
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        unsafeAtomicAdd(&ata[i * 4 + j], (double)r0[i] * (double)r0[j] + (double)r1[i] * (double)r1[j]);
+        contrib[c][i * 4 + j] = (double)r0[i] * (double)r0[j] + (double)r1[i] * (double)r1[j];
+  }
+  __syncthreads();
+  if (c < 16) {                                 // fixed order: the result does not depend on timing
+    double s = 0.0;
+    for (int k = 0; k < C; ++k) s += contrib[k][c];
+    ata[c] = s;
   }
   __syncthreads();
   if (c == 0) {
@@ -407,7 +413,8 @@ int launch_project_points(const float* pts, const float* cam, const float* intr,
 // ------------------------------------------------------------------ soft-argmax
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 
-// x: [T][Gh^3][Jp].  partial: [T][Jp][4] doubles (sum h, sum h*i, sum h*j, sum h*k),
+// x: [T][Gh^3][Jp].  partial: [T][Jp][4][kLimbs] doubles (sum h, sum h*i, sum h*j, sum h*k; order-
+// independent accumulation, jh_common.h),
 // pmax: [T][Jp] floats as ordered ints (h > 0 so the int order equals the float order).
 __global__ __launch_bounds__(256) void softargmax_partial_kernel(
     const float* __restrict__ x, double* __restrict__ partial, int* __restrict__ pmax, int Gh,
@@ -444,7 +451,7 @@ __global__ __launch_bounds__(256) void softargmax_partial_kernel(
     if (v < 4) {
       float acc = 0.f;
       for (int r = 0; r < rows; ++r) acc += sm[(((size_t)r * q + cq) * 5 + v) * 4 + comp];
-      unsafeAtomicAdd(partial + ((size_t)t * Jp + ch) * 4 + v, (double)acc);
+      exact_add(partial + (((size_t)t * Jp + ch) * 4 + v) * kLimbs, (double)acc);
     } else {
       float m = 0.f;
       for (int r = 0; r < rows; ++r) m = fmaxf(m, sm[(((size_t)r * q + cq) * 5 + v) * 4 + comp]);
@@ -460,7 +467,9 @@ __global__ void softargmax_final_kernel(const double* __restrict__ partial,
                                         float roi) {
   const int t = blockIdx.x, j = threadIdx.x;
   if (j >= J) return;
-  const double* p = partial + ((size_t)t * Jp + j) * 4;
+  const double* pl = partial + ((size_t)t * Jp + j) * 4 * kLimbs;
+  const double p[4] = {exact_read(pl), exact_read(pl + kLimbs), exact_read(pl + 2 * kLimbs),
+                       exact_read(pl + 3 * kLimbs)};
   const float norm = (float)p[0];
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
@@ -495,7 +504,7 @@ int launch_softargmax(const float* x, const int* center3d, double* partial, int*
   const int q = Jp / 4;
   JH_REQUIRE(q >= 1 && q <= 64 && J <= 256, "soft-argmax joint count");
   const int rows = 256 / q;
-  JH_CHECK_HIP(hipMemsetAsync(partial, 0, (size_t)T * Jp * 4 * sizeof(double), s));
+  JH_CHECK_HIP(hipMemsetAsync(partial, 0, (size_t)T * Jp * 4 * kLimbs * sizeof(double), s));
   JH_CHECK_HIP(hipMemsetAsync(pmax, 0, (size_t)T * Jp * sizeof(int), s));
   const int ppb = rows * 8;
   dim3 grid((P + ppb - 1) / ppb, T);

@@ -172,6 +172,38 @@ int launch_maxpool2(const Act& x, float* y, hipStream_t s);
 // again.  This bijection of [0, total) hands each XCD one CONTIGUOUS range of logical
 // blocks instead: XCD x runs logical blocks [start(x), start(x) + count(x)).
 struct BlockId { unsigned x, y, z; };
+
+// ---- order-independent statistics -------------------------------------------------------------
+// InstanceNorm statistics, squeeze-excite pools and soft-argmax sums are accumulated across
+// workgroups with fp64 atomics, whose order varies from run to run.  To make the result
+// independent of that order every addend is split into three limbs on fixed power-of-two grids
+// (2^16, 2^-20, 2^-56; what lies below 2^-56 is dropped, a function of the addend alone) and each
+// limb goes to its own accumulator: all addends of one accumulator are multiples of its grid
+// and the running sums stay far below 2^53 grid steps (<= 2^13 addends per accumulator), so EVERY
+// addition is exact and the sum does not depend on the order.  The three limb sums are added in
+// a fixed order by the reader.  A value therefore occupies kLimbs doubles; InstanceNorm
+// statistics are (sum, sum of squares) = kStatW doubles per (n, c).  An fp32 partial has at most
+// two non-zero limbs, usually one: the atomic count is what it was.
+constexpr int kLimbs = 3;
+constexpr int kStatW = 2 * kLimbs;
+#if defined(__HIPCC__)
+__device__ __forceinline__ void exact_add(double* dst, double p) {
+  const double h = rint(p * 0x1p-16) * 0x1p16;
+  const double r = p - h;
+  const double m = rint(r * 0x1p20) * 0x1p-20;
+  const double l = rint((r - m) * 0x1p56) * 0x1p-56;
+  if (h != 0.0) unsafeAtomicAdd(dst + 0, h);
+  if (m != 0.0) unsafeAtomicAdd(dst + 1, m);
+  if (l != 0.0) unsafeAtomicAdd(dst + 2, l);
+}
+__device__ __forceinline__ double exact_read(const double* src) { return (src[0] + src[1]) + src[2]; }
+// (sum, sum of squares) of one (n, c): st points at its kStatW doubles
+__device__ __forceinline__ void stat_add(double* st, float s1, float s2) {
+  exact_add(st, (double)s1);
+  exact_add(st + kLimbs, (double)s2);
+}
+#endif
+
 #if defined(__HIPCC__)
 __device__ __forceinline__ unsigned xcd_linear(unsigned L, unsigned total) {
   const unsigned q = total >> 3, r = total & 7u, x = L & 7u, s = L >> 3;

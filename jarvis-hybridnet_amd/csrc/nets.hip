@@ -116,7 +116,7 @@ int Plan::add_conv(const ParamMap& pm, const ConvDesc& d, const std::string& wke
   bytes_ += cw.phase_stride * d.nphase * sizeof(float);
   size_t off = 0;
   if (want_stats) {
-    off = scratch((size_t)y.N * y.Cp * 2);
+    off = scratch((size_t)y.N * y.Cp * kStatW);
     if (stats_off) *stats_off = off;
   }
   // algorithmic work: 2*MAC over the real (unpadded) channels; bytes = one read of
@@ -239,7 +239,7 @@ int EffTrackPlan::mbconv(const ParamMap& pm, const std::string& p, int stage, in
       for (int t = 0; t < k * k; ++t) wt[(size_t)t * raw.Cp + c] = w[(size_t)c * k * k + t];
     float* wd = nullptr;
     if (upload(wt, &wd)) return 1;
-    st1 = scratch((size_t)raw.N * raw.Cp * 2);
+    st1 = scratch((size_t)raw.N * raw.Cp * kStatW);
     push("depthwise_k" + std::to_string(k), 2.0 * raw.N * raw.pixels() * mid * k * k,
          8.0 * raw.N * raw.pixels() * mid, [this, e, wd, k, raw, st1](hipStream_t s) {
       return launch_depthwise(e, wd, k, raw.p, sc(st1), s);
@@ -248,7 +248,7 @@ int EffTrackPlan::mbconv(const ParamMap& pm, const std::string& p, int stage, in
   // _gn1 + swish: only its per-(n,c) pooled sums (squeeze-excite) are computed here; the
   // normalised tensor itself is never written -- the project conv re-applies
   // InstanceNorm + SiLU (+ the SE gate) while it stages its operand
-  const size_t pool = scratch((size_t)raw.N * raw.Cp);
+  const size_t pool = scratch((size_t)raw.N * raw.Cp * kLimbs);
   add_norm(raw, st1, ACT_SILU, nullptr, nullptr, nullptr, (long)pool);
   // squeeze-excite gate
   const float *wr, *br, *we, *be;
@@ -330,7 +330,7 @@ int EffTrackPlan::node(const ParamMap& pm, const std::string& cp, int n_in, cons
   if (pack_conv_weights(conv_desc(2, 1, 1, 0, cin, cout), pwh, bh, false, &cw)) return 1;
   convs_.push_back(cw);
   if (new_act(like.N, 1, like.H, like.W, cout, &out->a)) return 1;
-  const size_t st = scratch((size_t)like.N * out->a.Cp * 2);
+  const size_t st = scratch((size_t)like.N * out->a.Cp * kStatW);
   out->st = (long)st;
   out->inv = 1.f / (float)(like.H * like.W);
   NodeArgs a{};

@@ -110,24 +110,15 @@ def test_conv3d_winograd_equals_direct(cin, cout, D, H, W, monkeypatch):
     w = torch.randn(cout, cin, 3, 3, 3, generator=g) / (cin * 27) ** 0.5
     b = torch.randn(cout, generator=g) * 0.1
     y_w, ref = _conv(3, 0, 3, 1, 1, cin, cout, x, w, b, norm_act=1)
-    monkeypatch.setenv("JH_WINO_PP", "1")          # the two-wave-set ("ping-pong") form
-    y_p, _ = _conv(3, 0, 3, 1, 1, cin, cout, x, w, b, norm_act=1)
-    monkeypatch.delenv("JH_WINO_PP")
-    monkeypatch.setenv("JH_WINO_WS", "1")          # the wave-specialised form
-    y_s, _ = _conv(3, 0, 3, 1, 1, cin, cout, x, w, b, norm_act=1)
-    monkeypatch.delenv("JH_WINO_WS")
-    es = rel_err(y_s, ref)
-    report("conv3d_winograd_ws", cin=cin, cout=cout, rel=es)
-    assert es < 2e-4
     monkeypatch.setenv("JH_WINO_PW", "0")          # the one-role kernel (default: persistent form,
     y_q, _ = _conv(3, 0, 3, 1, 1, cin, cout, x, w, b, norm_act=1)   # which falls back to it here)
     monkeypatch.delenv("JH_WINO_PW")
     assert rel_err(y_q, ref) < 2e-4
     monkeypatch.setenv("JH_WINO", "0")
     y_d, _ = _conv(3, 0, 3, 1, 1, cin, cout, x, w, b, norm_act=1)
-    ew, ep, ed = rel_err(y_w, ref), rel_err(y_p, ref), rel_err(y_d, ref)
-    report("conv3d_winograd", cin=cin, cout=cout, rel_winograd=ew, rel_pingpong=ep, rel_direct=ed)
-    assert ew < 2e-4 and ep < 2e-4 and ed < 2e-4
+    ew, ed = rel_err(y_w, ref), rel_err(y_d, ref)
+    report("conv3d_winograd", cin=cin, cout=cout, rel_winograd=ew, rel_direct=ed)
+    assert ew < 2e-4 and ed < 2e-4
     assert not torch.equal(y_w, y_d), "JH_WINO had no effect"
 
 
@@ -177,4 +168,6 @@ def test_conv3d_winograd_persistent(cin, cout, N, G, in_norm, monkeypatch):
     e, e0 = rel_err(y, ref), rel_err(y0, ref)
     report("conv3d_winograd_persistent", cin=cin, cout=cout, n=N, g=G, rel=e, rel_one_role=e0)
     assert e < 2e-4 and e0 < 2e-4
-    assert not torch.equal(y, y0), "the persistent kernel did not run"
+    # the two kernels implement the same arithmetic in the same order: a launch may pick either
+    # (by its tile count) without changing a bit of the result
+    assert torch.equal(y, y0)
