@@ -220,6 +220,17 @@ int jh_op_conv(int nd, int kind, int k, int stride, int pad, int cin, int cout,
 int jh_op_depthwise(int k, int c, const float* w_host, const float* x_dev, int n, int h, int w,
                     int norm_act, float* y_dev, void* stream);
 
+/* One fused BiFPN node (jarvis/efficienttrack/model.py:301-353 fusion expressions + :223-232
+ * SeparableConvBlock.forward, without its trailing InstanceNorm):
+ *   y = pointwise(depthwise3x3(act(sum_i weights[i] * resample_i(InstanceNorm(x_i))))) + bias
+ * x_i (N,C,h_i,w_i) NCHW dev at the resolution its mode implies (0 same, 1 nearest x2 up from
+ * (h/2,w/2), 2 nearest x4 up from (h/4,w/4), 3 2x2 max-pool from (2h,2w)); modes / weights host
+ * arrays of 3; act 0 none / 2 SiLU; dw_host (C,1,3,3), pw_host (Cout,C), bias_host (Cout). */
+int jh_op_bifpn_node(int n_in, const int* modes, const float* weights, int act, int n, int c, int cout,
+                     int h, int w, const float* x0_dev, const float* x1_dev, const float* x2_dev,
+                     const float* dw_host, const float* pw_host, const float* bias_host, float* y_dev,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,6 +4,7 @@
 #include "../../include/jarvis_hip.h"
 #include <cstdlib>
 #include "nets.h"
+#include "bifpn_node.h"
 
 namespace jh {
 static thread_local std::string g_err;
@@ -637,6 +638,75 @@ int jh_op_depthwise(int k, int c, const float* w_host, const float* x_dev, int n
   if (launch_from_channel_last(y, y_dev, s)) return 1;
   JH_CHECK_HIP(hipStreamSynchronize(s));
   return 0;
+}
+
+
+// One fused BiFPN node (csrc/bifpn_node.hip) as a unit-test entry point: every input is a RAW
+// tensor that the node normalises on load with its own InstanceNorm statistics (computed here
+// on the host), exactly as inside the network plan.
+int jh_op_bifpn_node(int n_in, const int* modes, const float* weights, int act, int n, int c, int cout,
+                     int h, int w, const float* x0_dev, const float* x1_dev, const float* x2_dev,
+                     const float* dw_host, const float* pw_host, const float* bias_host, float* y_dev,
+                     void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  JH_REQUIRE(n_in >= 2 && n_in <= 3 && modes && weights && y_dev, "bad argument");
+  const float* xs[3] = {x0_dev, x1_dev, x2_dev};
+  Scratch sc;
+  Act in[3], y;
+  NodeArgs a{};
+  a.n_in = n_in; a.act = act;
+  for (int i = 0; i < n_in; ++i) {
+    int hi = h, wi = w;
+    if (modes[i] == FUSE_UP2) { hi = h / 2; wi = w / 2; }
+    else if (modes[i] == FUSE_UP4) { hi = h / 4; wi = w / 4; }
+    else if (modes[i] == FUSE_POOL2) { hi = h * 2; wi = w * 2; }
+    if (sc.act(n, 1, hi, wi, c, &in[i])) return 1;
+    if (launch_to_channel_last(xs[i], in[i], s)) return 1;
+    // statistics of the raw input (sum, sum of squares per (n, channel)), whole value in limb 1
+    const size_t px = (size_t)hi * wi;
+    std::vector<float> host((size_t)n * c * px);
+    JH_CHECK_HIP(hipMemcpyAsync(host.data(), xs[i], host.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+    JH_CHECK_HIP(hipStreamSynchronize(s));
+    std::vector<double> st((size_t)n * in[i].Cp * kStatW, 0.0);
+    for (int b = 0; b < n; ++b)
+      for (int ch = 0; ch < c; ++ch) {
+        double s1 = 0.0, s2 = 0.0;
+        const float* p = host.data() + ((size_t)b * c + ch) * px;
+        for (size_t k = 0; k < px; ++k) { s1 += p[k]; s2 += (double)p[k] * p[k]; }
+        st[((size_t)b * in[i].Cp + ch) * kStatW + 1] = s1;
+        st[((size_t)b * in[i].Cp + ch) * kStatW + kLimbs + 1] = s2;
+      }
+    double* std_dev;
+    if (sc.get(reinterpret_cast<void**>(&std_dev), st.size() * sizeof(double))) return 1;
+    JH_CHECK_HIP(hipMemcpyAsync(std_dev, st.data(), st.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    JH_CHECK_HIP(hipStreamSynchronize(s));                       // (st is a local)
+    a.in[i] = in[i].p; a.st[i] = std_dev; a.inv_cnt[i] = 1.f / (float)px; a.mode[i] = modes[i];
+    a.w[i] = weights[i];
+  }
+  if (sc.act(n, 1, h, w, cout, &y)) return 1;
+  JH_CHECK_HIP(hipMemsetAsync(y.p, 0, y.bytes(), s));
+  const int Cp = in[0].Cp;
+  std::vector<float> dwt((size_t)9 * Cp, 0.f);
+  for (int ch = 0; ch < c; ++ch)
+    for (int t = 0; t < 9; ++t) dwt[(size_t)t * Cp + ch] = dw_host[(size_t)ch * 9 + t];
+  float* dwd;
+  if (sc.get(reinterpret_cast<void**>(&dwd), dwt.size() * sizeof(float))) return 1;
+  JH_CHECK_HIP(hipMemcpyAsync(dwd, dwt.data(), dwt.size() * sizeof(float), hipMemcpyHostToDevice, s));
+  ConvWeights cw;
+  if (pack_conv_weights(conv_desc(2, 1, 1, 0, c, cout), pw_host, bias_host, false, &cw)) return 1;
+  double* ost;
+  int rc = 0;
+  do {
+    if ((rc = sc.get(reinterpret_cast<void**>(&ost), (size_t)n * y.Cp * kStatW * sizeof(double)))) break;
+    if (hipMemsetAsync(ost, 0, (size_t)n * y.Cp * kStatW * sizeof(double), s) != hipSuccess) { rc = 1; break; }
+    a.dw = dwd; a.pw = cw.w; a.bias = cw.bias; a.y = y.p; a.stats = ost;
+    a.N = n; a.H = h; a.W = w; a.Cp = Cp; a.cout_p = y.Cp; a.cout_p16 = cw.cout_p16;
+    if ((rc = launch_bifpn_node(a, s))) break;
+    if ((rc = launch_from_channel_last(y, y_dev, s))) break;
+    if (hipStreamSynchronize(s) != hipSuccess) { set_error("stream sync failed in jh_op_bifpn_node"); rc = 1; }
+  } while (0);
+  free_conv_weights(&cw);
+  return rc;
 }
 
 }  // extern "C"

@@ -171,3 +171,57 @@ def test_conv3d_winograd_persistent(cin, cout, N, G, in_norm, monkeypatch):
     # the two kernels implement the same arithmetic in the same order: a launch may pick either
     # (by its tile count) without changing a bit of the result
     assert torch.equal(y, y0)
+
+
+
+NODE_CASES = [  # (C, Cout, H, W, modes, act): the node shapes of the small / medium pyramids
+    (56, 56, 64, 64, (0, 1), 2),            # top-down P3: same level + nearest x2 of P4
+    (56, 56, 32, 32, (0, 0, 3), 2),         # bottom-up P4: two same-level inputs + 2x2 max-pool of P3
+    (56, 56, 8, 8, (0, 3), 2),              # P7 of the bottom-up pass
+    (56, 64, 64, 64, (0, 1, 2), 0),         # head: P3 + x2 P4 + x4 P5 -> first_conv (no activation)
+    (88, 88, 32, 32, (0, 0, 3), 2),         # medium model: wider pyramid (chunked halo path)
+]
+
+
+@pytest.mark.parametrize("C,Cout,H,W,modes,act", NODE_CASES)
+def test_bifpn_node(C, Cout, H, W, modes, act):
+    """One fused BiFPN node (csrc/bifpn_node.hip) against torch: InstanceNorm of every raw input
+    applied on load, fast-normalised weighted fusion with nearest up-sampling / 2x2 max-pooling
+    of the neighbour levels, SiLU, depthwise 3x3, pointwise 1x1 + bias -- the fusion expressions of
+    jarvis/efficienttrack/model.py:301-353 (+ :119-126 for the head) followed by
+    SeparableConvBlock.forward (:223-232) without its trailing InstanceNorm."""
+    import ctypes
+    from jarvis_hybridnet_amd import _native as N
+    g = torch.Generator().manual_seed(C + H + len(modes))
+    n = 3
+    shape = {0: (H, W), 1: (H // 2, W // 2), 2: (H // 4, W // 4), 3: (H * 2, W * 2)}
+    xs = [torch.randn(n, C, *shape[m], generator=g) * (1.0 + i) + 0.3 * i for i, m in enumerate(modes)]
+    wts = torch.rand(len(modes), generator=g) + 0.2
+    wts = wts / (wts.sum() + 1e-4)
+    dw = torch.randn(C, 1, 3, 3, generator=g) / 3
+    pw = torch.randn(Cout, C, generator=g) / C ** 0.5
+    bias = torch.randn(Cout, generator=g) * 0.1
+    fused = 0
+    for x, m, wk in zip(xs, modes, wts):
+        v = F.instance_norm(x, eps=1e-5)
+        if m == 1:
+            v = F.interpolate(v, scale_factor=2, mode="nearest")
+        elif m == 2:
+            v = F.interpolate(v, scale_factor=4, mode="nearest")
+        elif m == 3:
+            v = F.max_pool2d(v, 2, 2)
+        fused = fused + wk * v
+    if act == 2:
+        fused = F.silu(fused)
+    ref = F.conv2d(F.conv2d(fused, dw, None, 1, 1, 1, C), pw[:, :, None, None], bias)
+    dev = [cuda(x) for x in xs] + [None] * (3 - len(xs))
+    y = torch.empty(ref.shape, device="cuda")
+    m3 = (ctypes.c_int * 3)(*(list(modes) + [0] * (3 - len(modes))))
+    w3 = (ctypes.c_float * 3)(*([float(v) for v in wts] + [0.0] * (3 - len(modes))))
+    N.check(N.lib().jh_op_bifpn_node(len(modes), m3, w3, act, n, C, Cout, H, W, N.ptr(dev[0]), N.ptr(dev[1]),
+                                     N.ptr(dev[2]), dw.contiguous().data_ptr(), pw.contiguous().data_ptr(),
+                                     bias.contiguous().data_ptr(), y.data_ptr(), N.stream()))
+    torch.cuda.synchronize()
+    e = rel_err(y, ref)
+    report("bifpn_node", c=C, cout=Cout, h=H, modes=str(modes), rel=e)
+    assert e < 2e-5
