@@ -84,6 +84,13 @@ __global__ __launch_bounds__(512, 6) void bifpn_node_kernel(const NodeArgs a) {
 
   const int nk8 = Cp >> 3, nb = a.cout_p16 >> 4;
   const float2* wl = reinterpret_cast<const float2*>(a.pw) + lane;
+  if (a.abl & 16) {             // experiment: de-phase the first generation of workgroups
+    const unsigned L = blockIdx.x + gridDim.x * blockIdx.y;
+    if (L < 768u) {
+      const int k = (L >> 3) % 3;
+      for (int i = 0; i < k * (a.abl >> 8); ++i) __builtin_amdgcn_s_sleep(127);
+    }
+  }
 
   // 1 + 2. statistics -> mean / rstd, fused halo tile -> depthwise -> operand tile
   if constexpr (ONE) {
