@@ -56,7 +56,7 @@ __global__ __launch_bounds__(512, 6) void bifpn_node_kernel(const NodeArgs a) {
   // items in flight per thread: 512 x 5 covers a whole 56-channel halo tile in one round
   // trip; with three inputs that costs > 80 VGPRs, i.e. the third workgroup per CU, which
   // is worth more than the single round trip
-  constexpr int U = ONE ? (NIN == 3 ? 2 : 4) : (NIN == 3 ? 3 : 5);
+  constexpr int U = ONE ? ((NIN == 3 || M1 == FUSE_POOL2) ? 2 : 4) : (NIN == 3 ? 3 : 5);
   constexpr int NT = 512;                        // threads (8 waves: latency-bound prologue)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int Cp = a.Cp;
@@ -94,9 +94,18 @@ __global__ __launch_bounds__(512, 6) void bifpn_node_kernel(const NodeArgs a) {
 
   // 1 + 2. statistics -> mean / rstd, fused halo tile -> depthwise -> operand tile
   if constexpr (ONE) {
+    // Round 2: this kernel is bound by instruction issue (about 950 non-MFMA instructions per
+    // wave and tile at ~9 SIMD cycles each), the halo phase being the
+    // largest part, so it is written for instruction COUNT:
+    //  * InstanceNorm and the fusion weights are folded per channel into one multiply-add per
+    //    input, fused = sum_k x_k * a_k + B with a_k = w_k rstd_k and B = -sum_k w_k mean_k rstd_k
+    //    (computed once per workgroup by the statistics threads, held in registers by the
+    //    consumers: no per-item LDS reads, packed fp32 FMAs);
+    //  * halo pixels outside the image (the depthwise convolution's zero padding) are buffer
+    //    loads with bit 31 set in the offset -- out of range, they return 0 without a branch --
+    //    and one multiplication by 0 / 1 after the activation.
     // The statistics (and depthwise weights) are requested FIRST and consumed after the first
-    // batch of halo loads has been issued (loads return in order): the mean / rstd round trip
-    // runs under the halo round trip instead of in front of it.
+    // batch of halo loads has been issued (loads return in order).
     double sv0 = 0.0, sv1 = 0.0;
     bool has_st = false;
     const int sk = tid / Cp, scn = tid - sk * Cp;        // launcher: n_in * Cp <= 512
@@ -110,34 +119,51 @@ __global__ __launch_bounds__(512, 6) void bifpn_node_kernel(const NodeArgs a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) dwv[j] = tid + j * NT < 9 * Cp ? a.dw[tid + j * NT] : 0.f;
     bool first = true;
-    // Single channel chunk (Cp <= 64, operand tile aliased onto the halo tile).  The kernel
-    // is bound by vector-ALU issue, the halo phase by its index arithmetic, so this form has
-    // none to speak of: thread -> (channel quad c4 = tid % 16, pixel slot tid / 16), pixel
-    // coordinates advance incrementally (+32 pixels = +1 row +14 columns of the 18-wide
-    // halo tile), offsets are 32-bit relative to a uniform per-image base.  16 - q of every
-    // 16 lanes idle (q = 14 for the 56-channel pyramid).
+    // thread -> (channel quad c4 = tid % 16, pixel slot tid / 16); 16 - q of every 16 lanes idle
+    // (q = 14 for the 56-channel pyramid)
     const int q = Cp >> 2;
     const int c4 = tid & 15, slot = tid >> 4;
     const bool cact = c4 < q;
     const int c = c4 * 4;
     constexpr int NPX = kNodePY * kNodePX;
-    const float* inb[NIN];
+    typedef float nf2 __attribute__((ext_vector_type(2)));
+    typedef float nf4 __attribute__((ext_vector_type(4)));
+    __amdgpu_buffer_rsrc_t rs[NIN];
 #pragma unroll
-    for (int k = 0; k < NIN; ++k) inb[k] = a.in[k] + (size_t)n * node_plane(kModes[k], a.H, a.W) * Cp;
+    for (int k = 0; k < NIN; ++k) {
+      const size_t plane = node_plane(kModes[k], a.H, a.W) * Cp;
+      rs[k] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in[k] + (size_t)n * plane), 0,
+                                                (int)(plane * 4), 0x00020000);
+    }
+    nf2 ak[NIN][2], bb[2];                               // folded norm + fusion weights of this quad
     int py = slot >= kNodePX ? 1 : 0;
     int px = slot - py * kNodePX;
     int pix = slot;
     for (int p0 = 0; p0 < NPX; p0 += 32 * U) {
-      float4 v[U][NIN];
-      bool ok[U];
+      nf4 v[U][NIN];
+      float msk[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
-        ok[u] = cact && pix + u * 32 < NPX && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        const bool ok = cact && pix + u * 32 < NPX && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        msk[u] = ok ? 1.f : 0.f;
+        const unsigned oob = ok ? 0u : 0x80000000u;
 #pragma unroll
-        for (int k = 0; k < NIN; ++k)
-          v[u][k] = ok[u] ? node_fetch_n(inb[k], kModes[k], iy, ix, a.H, a.W, Cp, c)
-                          : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < NIN; ++k) {
+          if (kModes[k] == FUSE_POOL2) {                 // max commutes with the monotone IN map
+            const int w2 = a.W * 2;
+            const unsigned o = (unsigned)(((iy * 2 * w2 + ix * 2) * Cp + c) * 4) | oob;
+            const nf4 a0 = __builtin_bit_cast(nf4, __builtin_amdgcn_raw_buffer_load_b128(rs[k], o, 0, 0));
+            const nf4 a1 = __builtin_bit_cast(nf4, __builtin_amdgcn_raw_buffer_load_b128(rs[k], o, Cp * 4, 0));
+            const nf4 a2 = __builtin_bit_cast(nf4, __builtin_amdgcn_raw_buffer_load_b128(rs[k], o, w2 * Cp * 4, 0));
+            const nf4 a3 = __builtin_bit_cast(nf4, __builtin_amdgcn_raw_buffer_load_b128(rs[k], o, (w2 + 1) * Cp * 4, 0));
+            v[u][k] = __builtin_elementwise_max(__builtin_elementwise_max(a0, a1), __builtin_elementwise_max(a2, a3));
+          } else {
+            const int sh = kModes[k] == FUSE_UP2 ? 1 : (kModes[k] == FUSE_UP4 ? 2 : 0);
+            const unsigned o = (unsigned)((((iy >> sh) * (a.W >> sh) + (ix >> sh)) * Cp + c) * 4) | oob;
+            v[u][k] = __builtin_bit_cast(nf4, __builtin_amdgcn_raw_buffer_load_b128(rs[k], o, 0, 0));
+          }
+        }
         px += 32 - kNodePX; py += 1;
         if (px >= kNodePX) { px -= kNodePX; py += 1; }
       }
@@ -152,41 +178,47 @@ __global__ __launch_bounds__(512, 6) void bifpn_node_kernel(const NodeArgs a) {
             mean = (float)mu;
             rstd = (float)(1.0 / sqrt(var + 1e-5));
           }
-          mr_[sk * Cp + scn] = mean;
-          mr_[3 * Cp + sk * Cp + scn] = rstd;
+          const float ak1 = a.w[sk] * rstd;
+          mr_[sk * Cp + scn] = ak1;                      // a_k
+          mr_[3 * Cp + sk * Cp + scn] = -mean * ak1;     // b_k
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           if (tid + j * NT < 9 * Cp) dwl[tid + j * NT] = dwv[j];
         __syncthreads();
+        bb[0] = (nf2){0.f, 0.f}; bb[1] = bb[0];
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) {
+          const float4 av = cact ? *reinterpret_cast<const float4*>(mr_ + k * Cp + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4 bv = cact ? *reinterpret_cast<const float4*>(mr_ + 3 * Cp + k * Cp + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+          ak[k][0] = (nf2){av.x, av.y}; ak[k][1] = (nf2){av.z, av.w};
+          bb[0] += (nf2){bv.x, bv.y}; bb[1] += (nf2){bv.z, bv.w};
+        }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int pu = pix + u * 32;
         if (pu < NPX && cact) {
-          float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (ok[u]) {
+          nf2 lo = bb[0], hi = bb[1];
 #pragma unroll
-            for (int k = 0; k < NIN; ++k) {
-              float4 x = v[u][k];
-              const float4 mu = *reinterpret_cast<const float4*>(mr_ + k * Cp + c);
-              const float4 rs = *reinterpret_cast<const float4*>(mr_ + 3 * Cp + k * Cp + c);
-              x.x = (x.x - mu.x) * rs.x; x.y = (x.y - mu.y) * rs.y;
-              x.z = (x.z - mu.z) * rs.z; x.w = (x.w - mu.w) * rs.w;
-              const float wk = a.w[k];
-              if (k == 0) {
-                r = make_float4(__fmul_rn(wk, x.x), __fmul_rn(wk, x.y), __fmul_rn(wk, x.z), __fmul_rn(wk, x.w));
-              } else {
-                r.x = __fadd_rn(r.x, __fmul_rn(wk, x.x)); r.y = __fadd_rn(r.y, __fmul_rn(wk, x.y));
-                r.z = __fadd_rn(r.z, __fmul_rn(wk, x.z)); r.w = __fadd_rn(r.w, __fmul_rn(wk, x.w));
-              }
-            }
-            if (!(a.abl & 1)) {
-              r.x = node_act(r.x, a.act); r.y = node_act(r.y, a.act);
-              r.z = node_act(r.z, a.act); r.w = node_act(r.w, a.act);
-            }
+          for (int k = 0; k < NIN; ++k) {
+            lo = __builtin_elementwise_fma((nf2){v[u][k][0], v[u][k][1]}, ak[k][0], lo);
+            hi = __builtin_elementwise_fma((nf2){v[u][k][2], v[u][k][3]}, ak[k][1], hi);
           }
-          *reinterpret_cast<float4*>(Ft + pu * SF + c) = r;
+          if (!(a.abl & 1) && a.act == ACT_SILU) {
+            // x * sigmoid(x) with the hardware exp2 / reciprocal (about 1e-7 relative error)
+            const nf2 el = (nf2){__expf(-lo.x), __expf(-lo.y)} + (nf2){1.f, 1.f};
+            const nf2 eh = (nf2){__expf(-hi.x), __expf(-hi.y)} + (nf2){1.f, 1.f};
+            lo *= (nf2){__builtin_amdgcn_rcpf(el.x), __builtin_amdgcn_rcpf(el.y)};
+            hi *= (nf2){__builtin_amdgcn_rcpf(eh.x), __builtin_amdgcn_rcpf(eh.y)};
+          } else if (!(a.abl & 1) && a.act == ACT_RELU) {
+            lo = __builtin_elementwise_max(lo, (nf2){0.f, 0.f});
+            hi = __builtin_elementwise_max(hi, (nf2){0.f, 0.f});
+          }
+          const nf2 mm = (nf2){msk[u], msk[u]};
+          lo *= mm;
+          hi *= mm;
+          *reinterpret_cast<float4*>(Ft + pu * SF + c) = make_float4(lo.x, lo.y, hi.x, hi.y);
         }
       }
       pix += 32 * U;
@@ -201,24 +233,29 @@ __global__ __launch_bounds__(512, 6) void bifpn_node_kernel(const NodeArgs a) {
     const bool dact = cact && !(a.abl & 2);
     const bool bact = a.blds && tid * 8 < nk8 * nb * 128;
     const int sty = slot >> 2, stx = (slot & 3) * 4;
-    float4 dacc[4];
+    nf2 dlo[4], dhi[4];                          // packed fp32 FMAs: two channels per instruction
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dacc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < 4; ++i) { dlo[i] = (nf2){0.f, 0.f}; dhi[i] = dlo[i]; }
     if (dact) {
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy) {
-        float4 wv[3], xv[6];
+        nf2 wl2[3], wh2[3], xl[6], xh[6];
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) wv[dx] = *reinterpret_cast<const float4*>(dwl + (dy * 3 + dx) * Cp + c);
+        for (int dx = 0; dx < 3; ++dx) {
+          const float4 t = *reinterpret_cast<const float4*>(dwl + (dy * 3 + dx) * Cp + c);
+          wl2[dx] = (nf2){t.x, t.y}; wh2[dx] = (nf2){t.z, t.w};
+        }
 #pragma unroll
-        for (int j = 0; j < 6; ++j)
-          xv[j] = *reinterpret_cast<const float4*>(Ft + ((sty + dy) * kNodePX + stx + j) * SF + c);
+        for (int j = 0; j < 6; ++j) {
+          const float4 t = *reinterpret_cast<const float4*>(Ft + ((sty + dy) * kNodePX + stx + j) * SF + c);
+          xl[j] = (nf2){t.x, t.y}; xh[j] = (nf2){t.z, t.w};
+        }
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            dacc[i].x = fmaf(xv[i + dx].x, wv[dx].x, dacc[i].x); dacc[i].y = fmaf(xv[i + dx].y, wv[dx].y, dacc[i].y);
-            dacc[i].z = fmaf(xv[i + dx].z, wv[dx].z, dacc[i].z); dacc[i].w = fmaf(xv[i + dx].w, wv[dx].w, dacc[i].w);
+            dlo[i] = __builtin_elementwise_fma(xl[i + dx], wl2[dx], dlo[i]);
+            dhi[i] = __builtin_elementwise_fma(xh[i + dx], wh2[dx], dhi[i]);
           }
       }
     }
@@ -226,7 +263,8 @@ __global__ __launch_bounds__(512, 6) void bifpn_node_kernel(const NodeArgs a) {
     if (dact) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        *reinterpret_cast<float4*>(At + (sty * kNodeTX + stx + i) * SA + c) = dacc[i];
+        *reinterpret_cast<float4*>(At + (sty * kNodeTX + stx + i) * SA + c) =
+            make_float4(dlo[i].x, dlo[i].y, dhi[i].x, dhi[i].y);
     }
     if (bact) {                                  // (the barrier has passed: the halo tile is dead)
       const float4 b0 = *reinterpret_cast<const float4*>(a.pw + tid * 8);
@@ -353,6 +391,7 @@ __global__ __launch_bounds__(512, 6) void bifpn_node_kernel(const NodeArgs a) {
   e.bias = a.bias;
   e.stats = a.stats ? a.stats + (size_t)n * a.cout_p * kStatW : nullptr;
   e.Dout = 1; e.Hout = a.H; e.Wout = a.W; e.Hy = a.H; e.Wy = a.W;
+  const bool full_tile = oy0 + kNodeTY <= a.H && ox0 + kNodeTX <= a.W;      // (uniform)
   e.cout_p = a.cout_p; e.cout_p16 = a.cout_p16; e.os = 1; e.osz = 1; e.offz = e.offy = e.offx = 0;
   for (int nb0 = 0; nb0 < nb; nb0 += kNodeNRG) {
     f32x4 acc[1][kNodeNRG];
@@ -398,7 +437,10 @@ __global__ __launch_bounds__(512, 6) void bifpn_node_kernel(const NodeArgs a) {
       }
     }
     __syncthreads();          // the scratch may be the (dead) halo tile
-    if (!(a.abl & 8)) conv_epilogue<1, kNodeNRG, kNodeTY, kNodeTX, 8>(acc, e, red, nb0, 0, oy0, ox0, tid);
+    if (!(a.abl & 8)) {
+      if (full_tile) conv_epilogue<1, kNodeNRG, kNodeTY, kNodeTX, 8, true>(acc, e, red, nb0, 0, oy0, ox0, tid);
+      else conv_epilogue<1, kNodeNRG, kNodeTY, kNodeTX, 8>(acc, e, red, nb0, 0, oy0, ox0, tid);
+    }
     __syncthreads();
   }
 }

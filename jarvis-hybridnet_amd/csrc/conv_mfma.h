@@ -63,7 +63,8 @@ __device__ __forceinline__ float quad_xor2(float v) {
   return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
 }
 
-template <int MR, int NR, int TY, int TX, int NW = 4>
+// FULL: the caller guarantees that the whole tile lies inside the output (no bounds checks).
+template <int MR, int NR, int TY, int TX, int NW = 4, bool FULL = false>
 __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[MR][NR], const EpilogueArgs& e,
                                               float* red, int nb0, int oz0, int oy0, int ox0,
                                               int tid) {
@@ -83,7 +84,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[MR][NR], const Epilog
         const int p = (wave * MR + mr) * 16 + kq * 4 + r;
         const int tx = p % TX, ty = (p / TX) % TY, tz = p / (TX * TY);
         v[r] = acc[mr][nr][r] + bv;
-        if (ch_ok && oz0 + tz < e.Dout && oy0 + ty < e.Hout && ox0 + tx < e.Wout) {
+        if (ch_ok && (FULL || (oz0 + tz < e.Dout && oy0 + ty < e.Hout && ox0 + tx < e.Wout))) {
           s1 += v[r];
           s2 += v[r] * v[r];
         }
@@ -102,7 +103,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[MR][NR], const Epilog
       const int tx = p % TX, ty = (p / TX) % TY, tz = p / (TX * TY);
       const int oz = oz0 + tz, oy = oy0 + ty, ox = ox0 + tx;
       const int c0 = (nb0 + nr) * 16 + (mrow & ~3);
-      if (c0 < e.cout_p && oz < e.Dout && oy < e.Hout && ox < e.Wout)
+      if (c0 < e.cout_p && (FULL || (oz < e.Dout && oy < e.Hout && ox < e.Wout)))
         *reinterpret_cast<float4*>(
             e.y + ((size_t)((oz * e.osz + e.offz) * e.Hy + (oy * e.os + e.offy)) * e.Wy + (ox * e.os + e.offx)) * e.cout_p + c0) =
             make_float4(v[0], v[1], v[2], v[3]);
