@@ -480,6 +480,27 @@ def main():
             line["parity_max_abs_mm_vs_reference_fixture"] = float(
                 np.abs(res[0][0][0].cpu().numpy() - gold[0]).max())
 
+    if rank == 0 and not sharded and not args.no_secondary:
+        # ---- the reference's own call pattern: ONE multi-view frame set per forward (batch 1),
+        # stream-ordered back to back (no host sync inside the loop)
+        try:
+            p1 = NativePredictor(sd_c, sd_h, **common_kw(size, 1))
+            p1.set_calibration(*calib_dev)
+            f1 = fr[:1].contiguous()
+            o1 = (torch.empty((1, c["J"], 3), device=dev), torch.empty((1, c["J"]), device=dev),
+                  torch.empty((1,), device=dev, dtype=torch.int32))
+            for _ in range(10):
+                p1.forward(f1, o1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(100):
+                p1.forward(f1, o1)
+            torch.cuda.synchronize()
+            line["single_frame_latency_ms"] = 1e3 * (time.perf_counter() - t0) / 100
+            del p1
+        except Exception as e:
+            line["single_frame_latency_ms"] = repr(e)[:200]
+
     if rank == 0 and not sharded and not args.no_secondary and size == "small" and args.config == "cfg3":
         # ---- SURVEY 8d secondary line: the `medium` models (config.py's default size) on the
         # same workload, same method, fewer steps

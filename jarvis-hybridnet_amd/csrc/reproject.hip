@@ -161,6 +161,10 @@ __global__ __launch_bounds__(256) void repro_gather_kernel(
   float4 acc[Q];
 #pragma unroll
   for (int q = 0; q < Q; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  typedef float gf4 __attribute__((ext_vector_type(4)));
+  const size_t frame_floats = (size_t)C * Hh * Hh * Jp;     // (< 2^29: checked by the launcher)
+  const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(heat + (size_t)t * frame_floats), 0, (int)(frame_floats * 4), 0x00020000);
   __syncthreads();
 
   for (int cb = 0; cb < C; cb += kCamBatch) {
@@ -186,9 +190,11 @@ __global__ __launch_bounds__(256) void repro_gather_kernel(
       if (idx_out && vox_ok && cb + cc < C) idx_out[((size_t)(t * C + c)) * nvox + vox] = iv * hs + iu;
       // padded -> stored heatmap coordinates (the zero border may be virtual)
       const int hx = iu - 1 + heat_pad, hy = iv - 1 + heat_pad;
-      src[cc] = -1;
+      // byte offset inside frame t's heatmaps; taps on the (virtual) zero border get bit 31: the
+      // buffer load below is then out of range and returns 0 -- no branch, no 64-bit address
+      src[cc] = (int)0x80000000;
       if (cb + cc < C && hx >= 0 && hy >= 0 && hx < Hh && hy < Hh)
-        src[cc] = (((t * C + c) * Hh + hy) * Hh + hx) * Jp;
+        src[cc] = (((c * Hh + hy) * Hh + hx) * Jp) * 4;
     }
     float4 h[Q][kCamBatch];
 #pragma unroll
@@ -198,8 +204,8 @@ __global__ __launch_bounds__(256) void repro_gather_kernel(
 #pragma unroll
       for (int cc = 0; cc < kCamBatch; ++cc) {
         const int off = __shfl(src[cc], vsrc);
-        h[q][cc] = off >= 0 ? *reinterpret_cast<const float4*>(heat + (size_t)off + quad * 4)
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
+        const gf4 v = __builtin_bit_cast(gf4, __builtin_amdgcn_raw_buffer_load_b128(hrs, off + quad * 16, 0, 0));
+        h[q][cc] = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
 #pragma unroll
@@ -234,6 +240,7 @@ int launch_reproject(const float* cam, const float* intr, const float* dist, con
                      int heat_pad, int div255, hipStream_t s) {
   const int Gh = G / 2;
   JH_REQUIRE(G % 2 == 0 && Jp % 8 == 0 && Jp <= 64, "reprojection shape");
+  JH_REQUIRE((size_t)C * hs * hs * Jp * 4 < ((size_t)1 << 31), "heatmaps of one frame exceed 2 GB");
   ReproCalib cal{cam, intr, dist};
   const int nvc = Gh * Gh * Gh;
   hipLaunchKernelGGL(repro_coarse_kernel, dim3((nvc + 255) / 256, C, T), dim3(256), 0, s, cal,
