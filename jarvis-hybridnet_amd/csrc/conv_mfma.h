@@ -21,6 +21,7 @@
 // so no extra pass over the activation is required for the statistics.
 #pragma once
 #include <cstdlib>
+#include <type_traits>
 #include "jh_common.h"
 
 namespace jh {
@@ -223,6 +224,41 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   constexpr int ITER = (G::NPIX * Q4 + 255) / 256;
   constexpr bool PF = ITER <= 8;
   float4 pf[PF ? ITER : 1];
+  // PF kernels: the patch items of a thread are addressed ONCE -- byte offsets relative to the
+  // image, with bit 31 set for pixels outside it: a buffer load of such an offset is out of range
+  // and returns 0, which is the zero padding, without a branch; the channel pass is the scalar
+  // offset of the load.  (PMC on the 16-channel 128^2 layers: 8.5 vector-ALU instructions per
+  // MFMA, most of them the index arithmetic of staging, which ran three times per item and pass.)
+  // CQ: 256 is a multiple of the channel quads per pixel, so all items of a thread share one
+  // channel quad and its mean / rstd / gate are loaded once per pass.
+  constexpr bool CQ = (256 % Q4) == 0;
+  typedef float cf4 __attribute__((ext_vector_type(4)));
+  int pvo[PF ? ITER : 1];
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(xin), 0, (int)((size_t)a.Din * a.Hin * a.Win * a.in_px * 4), 0x00020000);
+  if constexpr (PF) {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int idx = tid + it * 256;
+      const int c4 = idx % Q4, pix = idx / Q4;
+      const int px = pix % G::PX;
+      const int py = (pix / G::PX) % G::PY;
+      const int pz = pix / (G::PX * G::PY);
+      const int iz = iz0 + pz, iy = iy0 + py, ix = ix0 + px;
+      const bool ok = idx < G::NPIX * Q4 && iz >= 0 && iz < a.Din && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+      pvo[it] = ok ? (((iz * a.Hin + iy) * a.Win + ix) * a.in_px + c4 * 4) * 4 : (int)0x80000000;
+    }
+  }
+  auto issue_pf = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int c4 = (tid + it * 256) % Q4;
+      // channels past the tensor (K padding of the last pass, the 3-channel network input) read 0
+      const int off = (c0 + c4 * 4 < a.in_px) ? pvo[it] : (int)0x80000000;
+      const cf4 v = __builtin_bit_cast(cf4, __builtin_amdgcn_raw_buffer_load_b128(xrs, off, c0 * 4, 0));
+      pf[it] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  };
   auto patch_ok = [&](int idx, int c0, const float** src) -> bool {
     const int c4 = idx % Q4;
     const int pix = idx / Q4;
@@ -254,14 +290,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     }
     return v;
   };
-  if constexpr (PF) {
-#pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-      const float* src;
-      const bool ok = patch_ok(tid + it * 256, 0, &src);
-      pf[it] = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
+  if constexpr (PF) issue_pf(0);
 
   // BREG: kernels whose whole weight set of a channel pass is small (1x1 convs, narrow 3x3
   // layers) fetch it into registers at the top of the pass, so the round trip to L2 runs under
@@ -283,19 +312,59 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     __syncthreads();
     // ---- stage the halo patch: [pixel][KC] with stride S; channels past cin_p read 0
     if constexpr (PF) {
-#pragma unroll
-      for (int it = 0; it < ITER; ++it) {
-        const int idx = tid + it * 256;
-        if (idx < G::NPIX * Q4) {
-          const float* src;
-          const bool ok = patch_ok(idx, c0, &src);
-          const int c4 = idx % Q4, pix = idx / Q4;
-          const float4 v = ok ? finish(pf[it], c0 + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-          float2* dst = lds2 + pix * S2 + c4 * 2;
-          dst[0] = make_float2(v.x, v.y);
-          dst[1] = make_float2(v.z, v.w);
+      // mode: 0 copy, 1 norm, 2 norm + relu, 3 norm + silu (dispatched once per pass, not per
+      // item); the gate multiplies in every mode
+      const int mode = !a.in_stats ? 0 : (a.in_act == ACT_RELU ? 2 : (a.in_act == ACT_SILU ? 3 : 1));
+      auto commit_pf = [&](auto mode_c) __attribute__((always_inline)) {
+        constexpr int MODE = decltype(mode_c)::value;
+        float4 mu0 = make_float4(0.f, 0.f, 0.f, 0.f), rs0 = make_float4(1.f, 1.f, 1.f, 1.f), gt0 = rs0;
+        if (CQ) {
+          const int cc = min(c0 + (tid % Q4) * 4, a.cin_p - 4);      // (clamped: such items are 0 anyway)
+          if (MODE != 0) {
+            mu0 = *reinterpret_cast<const float4*>(nrm + cc);
+            rs0 = *reinterpret_cast<const float4*>(nrm + a.cin_p + cc);
+          }
+          if (a.gate) gt0 = *reinterpret_cast<const float4*>(gate_l + cc);
         }
-      }
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+          const int idx = tid + it * 256;
+          if (idx < G::NPIX * Q4) {
+            const int c4 = idx % Q4, pix = idx / Q4;
+            float4 mu = mu0, rs = rs0, gt = gt0;
+            if (!CQ) {
+              const int cc = min(c0 + c4 * 4, a.cin_p - 4);
+              if (MODE != 0) {
+                mu = *reinterpret_cast<const float4*>(nrm + cc);
+                rs = *reinterpret_cast<const float4*>(nrm + a.cin_p + cc);
+              }
+              if (a.gate) gt = *reinterpret_cast<const float4*>(gate_l + cc);
+            }
+            float4 v = pf[it];
+            if (MODE != 0) {
+              // pixels outside the image and channels past the tensor (loaded as 0) stay 0
+              const float m = (pvo[it] < 0 || c0 + c4 * 4 >= a.in_px) ? 0.f : 1.f;
+              v.x = (v.x - mu.x) * rs.x; v.y = (v.y - mu.y) * rs.y;
+              v.z = (v.z - mu.z) * rs.z; v.w = (v.w - mu.w) * rs.w;
+              if (MODE == 2) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+              } else if (MODE == 3) {
+                v.x = __fdividef(v.x, 1.f + __expf(-v.x)); v.y = __fdividef(v.y, 1.f + __expf(-v.y));
+                v.z = __fdividef(v.z, 1.f + __expf(-v.z)); v.w = __fdividef(v.w, 1.f + __expf(-v.w));
+              }
+              v.x *= m; v.y *= m; v.z *= m; v.w *= m;
+            }
+            if (a.gate) { v.x *= gt.x; v.y *= gt.y; v.z *= gt.z; v.w *= gt.w; }
+            float2* dst = lds2 + pix * S2 + c4 * 2;
+            dst[0] = make_float2(v.x, v.y);
+            dst[1] = make_float2(v.z, v.w);
+          }
+        }
+      };
+      if (mode == 0) commit_pf(std::integral_constant<int, 0>{});
+      else if (mode == 3) commit_pf(std::integral_constant<int, 3>{});
+      else if (mode == 2) commit_pf(std::integral_constant<int, 2>{});
+      else commit_pf(std::integral_constant<int, 1>{});
     } else {
       for (int idx = tid; idx < G::NPIX * Q4; idx += 256) {
         const float* src;
@@ -310,14 +379,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     }
     __syncthreads();
     if constexpr (PF) {
-      if (c0 + KC < a.cin_p) {                   // next pass's loads fly under this pass's MFMAs
-#pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-          const float* src;
-          const bool ok = patch_ok(tid + it * 256, c0 + KC, &src);
-          pf[it] = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-      }
+      if (c0 + KC < a.cin_p) issue_pf(c0 + KC);  // next pass's loads fly under this pass's MFMAs
     }
 
     // Two forms of the tap loop.  PIPE (kernels with enough matrix work per tap): explicit
