@@ -545,7 +545,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   e.Dout = a.Dout; e.Hout = a.Hout; e.Wout = a.Wout; e.Hy = a.Hy; e.Wy = a.Wy;
   e.cout_p = a.cout_p; e.cout_p16 = a.cout_p16; e.os = a.ostride; e.osz = a.ostride;
   e.offz = a.phase[ph].ooff[0]; e.offy = a.phase[ph].ooff[1]; e.offx = a.phase[ph].ooff[2];
-  conv_epilogue<MR, NR, TY, TX>(acc, e, lds, nb0, oz0, oy0, ox0, tid);
+  // tiles entirely inside the output (all of them when the extents are multiples of the tile)
+  // take the epilogue without per-value bounds checks: with them every one of the 4 MR NR values
+  // of a lane costs an exec-masked block of a dozen instructions
+  if (oz0 + TZ <= a.Dout && oy0 + TY <= a.Hout && ox0 + TX <= a.Wout)
+    conv_epilogue<MR, NR, TY, TX, 4, true>(acc, e, lds, nb0, oz0, oy0, ox0, tid);
+  else
+    conv_epilogue<MR, NR, TY, TX>(acc, e, lds, nb0, oz0, oy0, ox0, tid);
 }
 
 // Channels per LDS pass: the candidate (8..32) that wastes the fewest zero-padded
