@@ -227,6 +227,9 @@ int pack_wino_weights(int cin, int cout, const float* w, const float* b, ConvWei
 int wino_variant_from_env();
 int launch_conv3d_wino(const ConvWeights& w, const Act& x, const Act& y, double* stats, hipStream_t s,
                        const InNorm* in, int variant = 4);
+// vector-ALU stem convolution 3 -> 16, k3 s2 p1 (csrc/stem.hip)
+void pack_stem_weights(const float* w_host, float* packed);
+int launch_stem_conv(const Act& x, const float* w_dev, const Act& y, double* stats, hipStream_t s);
 int launch_deconv_c1(const Act& x, const double* stats, float inv_cnt, int in_act, const float* w,
                      const Act& y, hipStream_t s);
 

@@ -379,8 +379,23 @@ int EffTrackPlan::build(const ParamMap& pm, const std::string& pre, int size, in
   if (new_act(N, 1, H / 2, W / 2, stem, &x.a)) return 1;
   size_t st = 0;
   const std::string bb = pre + "backbone_net.model.";
-  if (add_conv(pm, conv_desc(2, 3, 2, 1, 3, stem), bb + "_conv_stem.weight", "", false, input, x.a,
-               nullptr, true, &st)) return 1;
+  if (stem == 16 && JH_ENV_KNOB("JH_STEM_MFMA") <= 0) {
+    // the small model's 3 -> 16 stem runs on the vector ALUs (csrc/stem.hip): K = 27 is too
+    // little matrix work per workgroup for the MFMA kernel
+    const float* wh = nullptr;
+    if (get(pm, bb + "_conv_stem.weight", (size_t)16 * 27, &wh)) return 1;
+    std::vector<float> packed(27 * 16);
+    pack_stem_weights(wh, packed.data());
+    float* wd = nullptr;
+    if (upload(packed, &wd)) return 1;
+    st = scratch((size_t)N * 16 * kStatW);
+    const Act xin = input, xo = x.a;
+    const double opix = (double)N * xo.pixels();
+    push("conv2d_k3s2_3x16@" + std::to_string(xo.W), 2.0 * opix * 27 * 16,
+         4.0 * ((double)N * xin.pixels() * 3 + opix * 16 + 27 * 16),
+         [this, xin, xo, wd, st](hipStream_t s) { return launch_stem_conv(xin, wd, xo, sc(st), s); });
+  } else if (add_conv(pm, conv_desc(2, 3, 2, 1, 3, stem), bb + "_conv_stem.weight", "", false, input, x.a,
+                      nullptr, true, &st)) return 1;
   // the stem's InstanceNorm + swish is applied by the first block's conv on load
   x.st = (long)st;
   x.inv = 1.f / (float)((H / 2) * (W / 2));

@@ -1,0 +1,132 @@
+// Stem convolution of the EfficientNet trunk on the vector ALUs:
+// Conv2d(3 -> 16, k3, s2, p1, bias=False)  (jarvis/efficienttrack/efficientnet.py:150-152,
+// model.py:536-538; 16 = the `small` model's round_filters(32, 0.5)).
+//
+// On the MFMA path the 3 input channels are padded to 8 (K = 72 for 27 real taps) and every
+// workgroup spends several hundred staging / epilogue instructions on 36 MFMAs: 16 TFLOP/s, a
+// third of the HBM rate (2 MB per image in + out).  With K = 27 and N = 16 the op is a small dot
+// product per output pixel, so it runs as plain packed FMAs:
+//
+//   * 256 threads own a 16 x 16 tile of OUTPUT pixels; the 33 x 33 input halo tile (one float4
+//     r, g, b, 0 per pixel) is staged once in LDS, zero padding = out-of-range buffer loads;
+//   * a thread produces all 16 channels of one pixel: 9 taps x 3 channels x 16 packed-FMA lanes,
+//     the weights are LDS broadcasts ([tap][cin][16] floats);
+//   * raw output in the library's channel-last layout (four 16-byte stores per thread), and the
+//     per-(n, channel) sum / sum of squares of the tile for the InstanceNorm that follows
+//     (order-independent accumulation, jh_common.h).
+#include "jh_common.h"
+
+namespace jh {
+
+namespace {
+constexpr int kStT = 16, kStP = 2 * kStT + 1;       // output tile side, input patch side
+typedef float sf2 __attribute__((ext_vector_type(2)));
+typedef float sf4 __attribute__((ext_vector_type(4)));
+}  // namespace
+
+__global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ x,
+                                                        const float* __restrict__ w /* [9][3][16] */,
+                                                        float* __restrict__ y, double* __restrict__ stats,
+                                                        int H, int W) {
+  __shared__ __attribute__((aligned(16))) float4 patch[kStP * kStP];
+  __shared__ __attribute__((aligned(16))) float wl[27 * 16];
+  __shared__ float red[16 * 256];                    // statistics: [channel][thread]
+  __shared__ float red2[2 * 16 * 16];
+  const int tid = threadIdx.x;
+  const int Ho = H >> 1, Wo = W >> 1;
+  const int tiles_x = (Wo + kStT - 1) / kStT;
+  const BlockId bid = xcd_block();
+  const int oy0 = (bid.x / tiles_x) * kStT, ox0 = (bid.x % tiles_x) * kStT;
+  const int n = bid.y;
+  for (int i = tid; i < 27 * 16; i += 256) wl[i] = w[i];
+  // input patch: rows 2 oy0 - 1 .. 2 oy0 + 31, same in x
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(x + (size_t)n * H * W * 4), 0, H * W * 16, 0x00020000);
+  for (int i = tid; i < kStP * kStP; i += 256) {
+    const int py = i / kStP, px = i - py * kStP;
+    const int iy = 2 * oy0 - 1 + py, ix = 2 * ox0 - 1 + px;
+    const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+    const int off = ok ? (iy * W + ix) * 16 : (int)0x80000000;
+    const sf4 v = __builtin_bit_cast(sf4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+    patch[i] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+  __syncthreads();
+  const int ty = tid >> 4, tx = tid & 15;
+  sf2 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = (sf2){0.f, 0.f};
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const float4 in = patch[(2 * ty + ky) * kStP + 2 * tx + kx];
+      const float iv[3] = {in.x, in.y, in.z};
+#pragma unroll
+      for (int ci = 0; ci < 3; ++ci) {
+        const float4* wq = reinterpret_cast<const float4*>(wl + ((ky * 3 + kx) * 3 + ci) * 16);
+        const sf2 xv = (sf2){iv[ci], iv[ci]};
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const float4 wv = wq[q4];                  // (same address in every lane: broadcast)
+          acc[q4 * 2 + 0] = __builtin_elementwise_fma(xv, (sf2){wv.x, wv.y}, acc[q4 * 2 + 0]);
+          acc[q4 * 2 + 1] = __builtin_elementwise_fma(xv, (sf2){wv.z, wv.w}, acc[q4 * 2 + 1]);
+        }
+      }
+    }
+  const int oy = oy0 + ty, ox = ox0 + tx;
+  const bool in_img = oy < Ho && ox < Wo;
+  if (in_img) {
+    float4* dst = reinterpret_cast<float4*>(y + (((size_t)n * Ho + oy) * Wo + ox) * 16);
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4)
+      dst[q4] = make_float4(acc[q4 * 2][0], acc[q4 * 2][1], acc[q4 * 2 + 1][0], acc[q4 * 2 + 1][1]);
+  }
+  if (stats) {
+    // [channel][thread] (consecutive threads -> consecutive banks), then 16 threads per channel
+    // add 16 values each, then one thread per channel adds the 16 partials: a fixed order
+#pragma unroll
+    for (int c = 0; c < 16; ++c) red[c * 256 + tid] = in_img ? acc[c >> 1][c & 1] : 0.f;
+    __syncthreads();
+    {
+      const int c = tid >> 4, part = tid & 15;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float v = red[c * 256 + part * 16 + i];
+        s1 += v;
+        s2 = fmaf(v, v, s2);
+      }
+      red2[(c * 16 + part) * 2 + 0] = s1;
+      red2[(c * 16 + part) * 2 + 1] = s2;
+    }
+    __syncthreads();
+    if (tid < 16) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        s1 += red2[(tid * 16 + i) * 2 + 0];
+        s2 += red2[(tid * 16 + i) * 2 + 1];
+      }
+      stat_add(stats + ((size_t)n * 16 + tid) * kStatW, s1, s2);
+    }
+  }
+}
+
+// w_host: torch layout (16, 3, 3, 3) = [cout][cin][ky][kx]; w_dev receives [tap][cin][16]
+void pack_stem_weights(const float* w_host, float* packed /* 27 * 16 floats */) {
+  for (int co = 0; co < 16; ++co)
+    for (int ci = 0; ci < 3; ++ci)
+      for (int t = 0; t < 9; ++t) packed[(t * 3 + ci) * 16 + co] = w_host[(co * 3 + ci) * 9 + t];
+}
+
+int launch_stem_conv(const Act& x, const float* w_dev, const Act& y, double* stats, hipStream_t s) {
+  JH_REQUIRE(x.Cp == 4 && y.Cp == 16 && x.D == 1 && y.H * 2 == x.H && y.W * 2 == x.W && x.N == y.N,
+             "stem convolution shapes");
+  JH_REQUIRE((size_t)x.H * x.W * 16 < ((size_t)1 << 31), "stem input too large");
+  const int tiles = ((y.H + kStT - 1) / kStT) * ((y.W + kStT - 1) / kStT);
+  hipLaunchKernelGGL(stem_conv_kernel, dim3(tiles, x.N), dim3(256), 0, s, x.p, w_dev, y.p, stats, x.H, x.W);
+  JH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace jh
