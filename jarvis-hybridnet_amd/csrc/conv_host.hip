@@ -148,6 +148,10 @@ int launch_conv(const ConvDesc& d, const ConvWeights& w, const Act& x, const Act
   JH_REQUIRE(Do == y.D && Ho == y.H && Wo == y.W, "conv output extent mismatch");
   const int nr = pick_nr(w.cout_p16 / 16);
   const size_t budget = 72 * 1024;
+  if (d.nd == 2 && d.ostride == 2 && d.k == 2) {      // all four parities from one staged patch
+    const int rc = launch_deconv4_fused(a, s);
+    if (rc >= 0) return rc;
+  }
   if (d.nd == 2) {
     const int small = (a.Wout <= 8) ? 1 : 0;
     // 16 x 16 tiles for high-resolution layers with few input channels

@@ -135,6 +135,34 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[MR][NR], const Epilog
   }
 }
 
+// Epilogue of kernels that issue their MFMAs with the operands SWAPPED (weights as A, pixels as
+// B): the accumulator is then the transposed tile -- a lane holds, for pixel lane & 15 of the
+// block, the four consecutive channels 4 (lane >> 4) .. + 3 -- which is exactly one 16-byte
+// channel-last store: no 4 x 4 lane-quad transposes (16 of the ~34 instructions per block of
+// the epilogue above).  The per-channel statistics would need a 16-lane reduction in this
+// layout, so it is used for layers WITHOUT fused statistics only (the heads' last layers).
+template <int MR, int NR, int TY, int TX, bool FULL>
+__device__ __forceinline__ void conv_epilogue_tr(f32x4 (&acc)[MR][NR], const EpilogueArgs& e, int nb0,
+                                                 int oz0, int oy0, int ox0, int tid) {
+  const int lane = tid & 63, wave = tid >> 6, mrow = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int nr = 0; nr < NR; ++nr) {
+    const int c0 = (nb0 + nr) * 16 + kq * 4;
+    f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (e.bias && c0 < e.cout_p16) bv = *reinterpret_cast<const f32x4*>(e.bias + c0);
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) {
+      const int p = (wave * MR + mr) * 16 + mrow;
+      const int tx = p % TX, ty = (p / TX) % TY, tz = p / (TX * TY);
+      const int oz = oz0 + tz, oy = oy0 + ty, ox = ox0 + tx;
+      const f32x4 v = acc[mr][nr] + bv;
+      if (c0 < e.cout_p && (FULL || (oz < e.Dout && oy < e.Hout && ox < e.Wout)))
+        *reinterpret_cast<f32x4*>(
+            e.y + ((size_t)((oz * e.osz + e.offz) * e.Hy + (oy * e.os + e.offy)) * e.Wy + (ox * e.os + e.offx)) * e.cout_p + c0) = v;
+    }
+  }
+}
+
 template <int ND, int K, int STRIDE, int TZ, int TY, int TX, int NR, int KC8>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   using G = ConvGeom<ND, K, STRIDE, TZ, TY, TX>;
@@ -609,6 +637,9 @@ int launch_conv_geom(const ConvArgs& a, int nr, size_t lds_budget, hipStream_t s
 #undef JH_CONV_CASE
   JH_REQUIRE(false, "bad (NR, KC8)");
 }
+
+// ConvTranspose2d k4 s2 p1 with the four parities in one workgroup (csrc/deconv4.hip); -1: not its layer
+int launch_deconv4_fused(const ConvArgs& a, hipStream_t s);
 
 // per-translation-unit entry points (one .hip file per kernel family so the
 // instantiations compile in parallel)
