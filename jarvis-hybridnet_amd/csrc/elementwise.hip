@@ -171,7 +171,8 @@ __global__ __launch_bounds__(256) void depthwise_lds_kernel(
     const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
     double* __restrict__ stats, int H, int W, int Cp) {
   constexpr int T = 16, HT = T + K - 1, CC = 32, SP = CC + 4;
-  extern __shared__ __attribute__((aligned(16))) float sm[];     // [HT*HT][SP]
+  extern __shared__ __attribute__((aligned(16))) float sm[];     // [HT*HT][SP], then [K*K][CC] weights
+  float* wl = sm + HT * HT * SP;
   const int tid = threadIdx.x;
   const int tiles_x = (W + T - 1) / T;
   const BlockId bid = xcd_block();
@@ -179,64 +180,62 @@ __global__ __launch_bounds__(256) void depthwise_lds_kernel(
   const int c0 = bid.y * CC;
   const int n = bid.z;
   const int q = min(CC, Cp - c0) >> 2;             // channel quads in this chunk (<= 8)
-  const float* xin = x + (size_t)n * H * W * Cp;
-  // halo patch: thread -> (channel quad tid % 8, pixel slot tid / 8); the loop has a
-  // compile-time trip count and all loads of a batch are issued before the first LDS store
-  // (a load -> store loop with a run-time bound kept ONE load in flight per thread and
-  // cost ~25 us per workgroup)
-  {
-    constexpr int NPX = HT * HT, ITERS = (NPX + 31) / 32, UB = 7;
-    const int lc4 = tid & 7, slot = tid >> 3;
+  typedef float df2 __attribute__((ext_vector_type(2)));
+  typedef float df4 __attribute__((ext_vector_type(4)));
+  // The kernel is latency-bound (two workgroups per CU, ~900 instructions per wave): everything it
+  // needs from memory is requested in ONE round trip -- the weights of the chunk first, then the
+  // whole halo patch (thread -> channel quad tid % 8, pixel slot tid / 8; pixels outside the image
+  // and quads past the tensor are out-of-range buffer loads, i.e. the zero padding, no branches).
+  const int lc4 = tid & 7, slot = tid >> 3;
+  df4 wv = (df4){0.f, 0.f, 0.f, 0.f};
+  if (tid < K * K * 8 && lc4 < q)
+    wv = *reinterpret_cast<const df4*>(w + (size_t)(tid >> 3) * Cp + c0 + lc4 * 4);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(x + (size_t)n * H * W * Cp), 0, (int)((size_t)H * W * Cp * 4), 0x00020000);
+  constexpr int NPX = HT * HT, ITERS = (NPX + 31) / 32;
+  df4 v[ITERS];
 #pragma unroll
-    for (int it0 = 0; it0 < ITERS; it0 += UB) {
-      float4 v[UB];
+  for (int u = 0; u < ITERS; ++u) {
+    const int pix = u * 32 + slot;
+    const int px = pix % HT, py = pix / HT;
+    const int iy = oy0 + py - K / 2, ix = ox0 + px - K / 2;
+    const bool ok = pix < NPX && lc4 < q && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    const int off = ok ? ((iy * W + ix) * Cp + c0 + lc4 * 4) * 4 : (int)0x80000000;
+    v[u] = __builtin_bit_cast(df4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+  }
+  if (tid < K * K * 8) *reinterpret_cast<df4*>(wl + (tid >> 3) * CC + lc4 * 4) = wv;
 #pragma unroll
-      for (int u = 0; u < UB; ++u) {
-        const int pix = (it0 + u) * 32 + slot;
-        const int px = pix % HT, py = pix / HT;
-        const int iy = oy0 + py - K / 2, ix = ox0 + px - K / 2;
-        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (it0 + u < ITERS && pix < NPX && lc4 < q && iy >= 0 && iy < H && ix >= 0 && ix < W)
-          v[u] = *reinterpret_cast<const float4*>(xin + ((size_t)iy * W + ix) * Cp + c0 + lc4 * 4);
-      }
-#pragma unroll
-      for (int u = 0; u < UB; ++u) {
-        const int pix = (it0 + u) * 32 + slot;
-        if (it0 + u < ITERS && pix < NPX && lc4 < q) *reinterpret_cast<float4*>(sm + pix * SP + lc4 * 4) = v[u];
-      }
-    }
+  for (int u = 0; u < ITERS; ++u) {
+    const int pix = u * 32 + slot;
+    if (pix < NPX) *reinterpret_cast<df4*>(sm + pix * SP + lc4 * 4) = v[u];
   }
   const int c4 = tid & 7;                          // fixed channel quad of this thread
   const bool active = c4 < q;
-  float4 wt[K * K];
-  if (active) {
-#pragma unroll
-    for (int t = 0; t < K * K; ++t)
-      wt[t] = *reinterpret_cast<const float4*>(w + (size_t)t * Cp + c0 + c4 * 4);
-  }
   __syncthreads();
-  float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
+  df2 s1l = (df2){0.f, 0.f}, s1h = s1l, s2l = s1l, s2h = s1l;
   if (active) {
-#pragma unroll
+#pragma unroll 1
     for (int j = 0; j < 2; ++j) {
       const int g = (tid >> 3) + 32 * j;           // 64 strips: 16 rows x 4 strips of 4 pixels
       const int ty = g >> 2, tx0 = (g & 3) * 4;
-      float4 acc[4];
+      df2 al[4], ah[4];                            // packed fp32 FMAs: two channels per instruction
 #pragma unroll
-      for (int o = 0; o < 4; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
+      for (int o = 0; o < 4; ++o) { al[o] = (df2){0.f, 0.f}; ah[o] = al[o]; }
+#pragma unroll 1
       for (int dy = 0; dy < K; ++dy) {
-        float4 in[K + 3];
+        df4 in[K + 3], kw[K];
+#pragma unroll
+        for (int dx = 0; dx < K; ++dx) kw[dx] = *reinterpret_cast<const df4*>(wl + (dy * K + dx) * CC + c4 * 4);
 #pragma unroll
         for (int i = 0; i < K + 3; ++i)
-          in[i] = *reinterpret_cast<const float4*>(sm + ((ty + dy) * HT + tx0 + i) * SP + c4 * 4);
+          in[i] = *reinterpret_cast<const df4*>(sm + ((ty + dy) * HT + tx0 + i) * SP + c4 * 4);
 #pragma unroll
         for (int dx = 0; dx < K; ++dx) {
-          const float4 k = wt[dy * K + dx];
+          const df2 kl = (df2){kw[dx][0], kw[dx][1]}, kh = (df2){kw[dx][2], kw[dx][3]};
 #pragma unroll
           for (int o = 0; o < 4; ++o) {
-            acc[o].x = fmaf(in[o + dx].x, k.x, acc[o].x); acc[o].y = fmaf(in[o + dx].y, k.y, acc[o].y);
-            acc[o].z = fmaf(in[o + dx].z, k.z, acc[o].z); acc[o].w = fmaf(in[o + dx].w, k.w, acc[o].w);
+            al[o] = __builtin_elementwise_fma((df2){in[o + dx][0], in[o + dx][1]}, kl, al[o]);
+            ah[o] = __builtin_elementwise_fma((df2){in[o + dx][2], in[o + dx][3]}, kh, ah[o]);
           }
         }
       }
@@ -245,25 +244,37 @@ __global__ __launch_bounds__(256) void depthwise_lds_kernel(
       for (int o = 0; o < 4; ++o) {
         const int ox = ox0 + tx0 + o;
         if (oy < H && ox < W) {
-          *reinterpret_cast<float4*>(y + (((size_t)n * H + oy) * W + ox) * Cp + c0 + c4 * 4) = acc[o];
-          s1.x += acc[o].x; s1.y += acc[o].y; s1.z += acc[o].z; s1.w += acc[o].w;
-          s2.x += acc[o].x * acc[o].x; s2.y += acc[o].y * acc[o].y;
-          s2.z += acc[o].z * acc[o].z; s2.w += acc[o].w * acc[o].w;
+          *reinterpret_cast<df4*>(y + (((size_t)n * H + oy) * W + ox) * Cp + c0 + c4 * 4) =
+              (df4){al[o][0], al[o][1], ah[o][0], ah[o][1]};
+          s1l += al[o]; s1h += ah[o];
+          s2l += al[o] * al[o]; s2h += ah[o] * ah[o];
         }
       }
     }
   }
   if (stats) {
     __syncthreads();                               // the patch is dead: reuse LDS for the reduce
-    // [32 rows][8 quads][2][4]
-    float4* p = reinterpret_cast<float4*>(sm) + ((size_t)(tid >> 3) * 8 + c4) * 2;
-    p[0] = s1; p[1] = s2;
+    // [32 rows][8 quads][2][4]; fixed-order two-level sum (8 threads x 4 rows, then 8 partials)
+    df4* p = reinterpret_cast<df4*>(sm) + ((size_t)(tid >> 3) * 8 + c4) * 2;
+    p[0] = (df4){s1l[0], s1l[1], s1h[0], s1h[1]};
+    p[1] = (df4){s2l[0], s2l[1], s2h[0], s2h[1]};
+    float* red2 = sm + 32 * 8 * 8;                 // [64 values][8 parts]
+    __syncthreads();
+    for (int i = tid; i < q * 8 * 8; i += 256) {
+      const int part = i & 7, val = i >> 3;        // val = (quad, sum / sum of squares, component)
+      const int comp = val & 3, sq = (val >> 2) & 1, cq = val >> 3;
+      float acc = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc += sm[(((size_t)(part * 4 + r) * 8 + cq) * 2 + sq) * 4 + comp];
+      red2[val * 8 + part] = acc;
+    }
     __syncthreads();
     for (int i = tid; i < q * 8; i += 256) {
-      const int comp = i & 3, v = (i >> 2) & 1, cq = i >> 3;
+      const int comp = i & 3, sq = (i >> 2) & 1, cq = i >> 3;
       float acc = 0.f;
-      for (int r = 0; r < 32; ++r) acc += sm[(((size_t)r * 8 + cq) * 2 + v) * 4 + comp];
-      exact_add(stats + (((size_t)n * Cp + c0 + cq * 4 + comp) * 2 + v) * kLimbs, (double)acc);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) acc += red2[i * 8 + r];
+      exact_add(stats + (((size_t)n * Cp + c0 + cq * 4 + comp) * 2 + sq) * kLimbs, (double)acc);
     }
   }
 }
@@ -274,8 +285,8 @@ int launch_depthwise(const Act& x, const float* w, int k, float* y, double* stat
   const int tiles = ((x.H + 15) / 16) * ((x.W + 15) / 16);
   dim3 grid(tiles, (x.Cp + 31) / 32, x.N);
   const int ht = 16 + k - 1;
-  size_t lds = (size_t)ht * ht * 36 * sizeof(float);
-  if (lds < 32 * 8 * 8 * sizeof(float)) lds = 32 * 8 * 8 * sizeof(float);
+  size_t lds = (size_t)(ht * ht * 36 + k * k * 32) * sizeof(float);
+  if (lds < (32 * 8 * 8 + 64 * 8) * sizeof(float)) lds = (32 * 8 * 8 + 64 * 8) * sizeof(float);
   if (k == 3)
     hipLaunchKernelGGL(depthwise_lds_kernel<3>, grid, dim3(256), lds, s, x.p, w, y, stats, x.H, x.W, x.Cp);
   else
