@@ -8,7 +8,7 @@
 //
 //   * 256 threads own an 8 x 16 tile of INPUT pixels; the 10 x 18 halo tile is staged once in
 //     LDS with the producer's InstanceNorm(+act) applied on load (as conv_mfma.h does);
-//   * wave pairs split by output-row parity (wave-uniform, so the weights are LDS broadcasts);
+//   * wave pairs split by output-row parity (wave-uniform, so the weights are scalar loads);
 //     a thread produces the two horizontally adjacent outputs (2m+py, 2n), (2m+py, 2n+1) from
 //     2 rows x 3 columns of the tile;
 //   * output in the library's channel-last layout [N][2H][2W][cout_p] (pad channels 0), one
@@ -28,8 +28,7 @@ __global__ __launch_bounds__(256) void deconv_c1_kernel(
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int S = Cp + 4;                          // pixel stride: 16 lanes x b128 conflict-free
   float* nrm = sm;                               // [Cp] mean, [Cp] rstd
-  float* wl = nrm + 2 * Cp;                      // [16][Cp]
-  float* tile = wl + 16 * Cp;                    // [180][S]
+  float* tile = nrm + 2 * Cp;                    // [180][S]
   const int tid = threadIdx.x;
   const BlockId bid = xcd_block();
   const int tiles_x = (W + kDcTX - 1) / kDcTX;
@@ -37,7 +36,6 @@ __global__ __launch_bounds__(256) void deconv_c1_kernel(
   const int n = bid.y;
   const int q = Cp >> 2;
 
-  for (int i = tid; i < 16 * Cp; i += 256) wl[i] = w[i];
   for (int c = tid; c < Cp; c += 256) {
     float mean = 0.f, rstd = 1.f;
     if (st) {
@@ -56,7 +54,7 @@ __global__ __launch_bounds__(256) void deconv_c1_kernel(
   // halo tile: thread -> (channel quad tid % 16, pixel slot tid / 16), compile-time trip count,
   // the loads of a batch issued before the first LDS store
   {
-    constexpr int NPX = kDcPY * kDcPX, ITERS = (NPX + 15) / 16, UB = 6;
+    constexpr int NPX = kDcPY * kDcPX, ITERS = (NPX + 15) / 16, UB = ITERS;    // one round trip
     const int slot = tid >> 4;
    for (int cq0 = 0; cq0 < q; cq0 += 16) {       // 16 channel quads at a time (one for cin <= 64)
     const int lc4 = cq0 + (tid & 15);
@@ -110,8 +108,11 @@ __global__ __launch_bounds__(256) void deconv_c1_kernel(
   const int rb = py ? tm + 1 : tm, kb = py ? 2 : 3;
   const float* ta = tile + (ra * kDcPX + tn) * S;            // columns n-1, n, n+1 at +0, +S, +2S
   const float* tb = tile + (rb * kDcPX + tn) * S;
-  const float* wa = wl + ka * 4 * Cp;                        // [kx][Cp]
-  const float* wb = wl + kb * 4 * Cp;
+  // The weights are wave-uniform (py is): they are read through the scalar cache into SGPRs
+  // instead of as LDS broadcasts -- the kernel was LDS-bandwidth-bound with 8 weight + 6 data
+  // quads per 4 channels.
+  const float* __restrict__ wa = w + ka * 4 * Cp;            // [kx][Cp]
+  const float* __restrict__ wb = w + kb * 4 * Cp;
   float o0 = 0.f, o1 = 0.f;
   for (int c = 0; c < Cp; c += 4) {
     const float4 a0 = *reinterpret_cast<const float4*>(ta + c);
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256) void deconv_c1_kernel(
 int launch_deconv_c1(const Act& x, const double* stats, float inv_cnt, int in_act, const float* w,
                      const Act& y, hipStream_t s) {
   JH_REQUIRE(y.H == 2 * x.H && y.W == 2 * x.W && y.N == x.N && y.C == 1, "deconv_c1 shapes");
-  const size_t lds = ((size_t)2 * x.Cp + 16 * x.Cp + (size_t)kDcPY * kDcPX * (x.Cp + 4)) * sizeof(float);
+  const size_t lds = ((size_t)2 * x.Cp + (size_t)kDcPY * kDcPX * (x.Cp + 4)) * sizeof(float);
   JH_REQUIRE(lds <= 160 * 1024, "deconv_c1 tile does not fit LDS");
   static bool big = false;
   if (lds > 64 * 1024 && !big) {
