@@ -67,6 +67,8 @@ int pack_conv_weights(const ConvDesc& d, const float* w, const float* b, bool tr
   const int nk8 = cin_p / 8, nb = cout_p16 / 16;
   const size_t phase_stride = (size_t)ntap * nk8 * nb * 128;
   std::vector<float> packed(phase_stride * d.nphase, 0.f);
+  // kernels that read both operands 16 bytes at a time want two 8-channel steps per lane word
+  const bool paired = d.nd == 2 && d.ostride > 1 && deconv4_eligible(cin_p, cout_p16);
   // geometry of the source tensor
   int skd, sk;   // source kernel extents
   if (d.ostride > 1 && d.nd == 2) { skd = 1; sk = 4; }
@@ -93,11 +95,14 @@ int pack_conv_weights(const ConvDesc& d, const float* w, const float* b, bool tr
               const int kc8 = ci / 8, kq = (ci % 8) / 2, j = ci % 2;
               const int nbk = co / 16, nn = co % 16;
               const int lane = kq * 16 + nn;
-              packed[ph * phase_stride + (((size_t)tap * nk8 + kc8) * nb + nbk) * 128 + lane * 2 + j] = v;
+              if (paired)
+                packed[ph * phase_stride + (((size_t)tap * (nk8 / 2) + kc8 / 2) * nb + nbk) * 256 + lane * 4 + (kc8 & 1) * 2 + j] = v;
+              else
+                packed[ph * phase_stride + (((size_t)tap * nk8 + kc8) * nb + nbk) * 128 + lane * 2 + j] = v;
             }
         }
   }
-  out->cin_p = cin_p; out->cout_p16 = cout_p16; out->phase_stride = phase_stride;
+  out->cin_p = cin_p; out->cout_p16 = cout_p16; out->phase_stride = phase_stride; out->paired = paired ? 1 : 0;
   JH_CHECK_HIP(hipMalloc(&out->w, packed.size() * sizeof(float)));
   JH_CHECK_HIP(hipMemcpy(out->w, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
   out->bias = nullptr;
@@ -139,7 +144,7 @@ int launch_conv(const ConvDesc& d, const ConvWeights& w, const Act& x, const Act
   if (gate) a.nrm_floats += w.cin_p;            // the gate vector of the image, behind mean / rstd
   a.N = x.N; a.Din = x.D; a.Hin = x.H; a.Win = x.W; a.cin_p = w.cin_p; a.in_px = x.Cp;
   a.Dy = y.D; a.Hy = y.H; a.Wy = y.W; a.cout_p = y.Cp; a.cout_p16 = w.cout_p16;
-  a.ostride = d.ostride; a.nphase = d.nphase; a.phase_stride = w.phase_stride;
+  a.ostride = d.ostride; a.nphase = d.nphase; a.phase_stride = w.phase_stride; a.paired = w.paired;
   for (int p = 0; p < d.nphase; ++p) a.phase[p] = d.phase[p];
   if (d.ostride > 1) { a.Dout = x.D; a.Hout = x.H; a.Wout = x.W; }
   else conv_out_shape(d, x.D, x.H, x.W, &a.Dout, &a.Hout, &a.Wout);
@@ -152,6 +157,7 @@ int launch_conv(const ConvDesc& d, const ConvWeights& w, const Act& x, const Act
     const int rc = launch_deconv4_fused(a, s);
     if (rc >= 0) return rc;
   }
+  JH_REQUIRE(!a.paired, "paired weight layout without a kernel that reads it");
   if (d.nd == 2) {
     const int small = (a.Wout <= 8) ? 1 : 0;
     // 16 x 16 tiles for high-resolution layers with few input channels

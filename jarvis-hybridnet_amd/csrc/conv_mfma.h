@@ -640,6 +640,7 @@ int launch_conv_geom(const ConvArgs& a, int nr, size_t lds_budget, hipStream_t s
 
 // ConvTranspose2d k4 s2 p1 with the four parities in one workgroup (csrc/deconv4.hip); -1: not its layer
 int launch_deconv4_fused(const ConvArgs& a, hipStream_t s);
+bool deconv4_eligible(int cin_p, int cout_p16);
 
 // per-translation-unit entry points (one .hip file per kernel family so the
 // instantiations compile in parallel)

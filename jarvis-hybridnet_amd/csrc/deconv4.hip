@@ -16,6 +16,13 @@
 // the same 16 (parity, tap) MFMA groups.  Per parity the taps are visited in the order of the
 // general kernel and the per-workgroup statistics cover the same pixels, so outputs and fused
 // statistics are bit-identical to it (JH_DECONV_FUSED=0 selects the general kernel).
+//
+// Operand layout ("paired"): in an fp32 MFMA stream every LDS read costs ~24 cycles and every
+// global load ~36 cycles of issue whatever its width (tools/mfma_valu_coissue.hip), against 32 per
+// MFMA, so both operands are read 16 bytes at a time: the patch keeps the channels of two
+// consecutive 8-channel steps interleaved per lane quarter ([kq][step parity][2]), the weights are
+// packed as [tap][step pair][column block][lane][4] (pack_conv_weights, ConvWeights::paired) --
+// one ds_read_b128 / global_load_dwordx4 feeds four MFMAs instead of two.
 #include <type_traits>
 #include "conv_mfma.h"
 
@@ -30,7 +37,8 @@ constexpr int kDSPAD = 4;
 template <int NRP, int KC8, bool TR>
 __global__ __launch_bounds__(256) void deconv4_fused_kernel(const ConvArgs a) {
   constexpr int MR = 2, NR = 4 * NRP;
-  constexpr int KC = KC8 * 8, S = KC + kDSPAD, S2 = S / 2, Q4 = KC / 4;
+  constexpr int KC = KC8 * 8, S = KC + kDSPAD, S2 = S / 2, Q4 = KC / 4, KP = KC8 / 2;
+  static_assert(KC8 % 2 == 0 && S2 % 2 == 0, "paired operand layout");
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
   float* nrm = lds_all;                         // [cin_p] mean, [cin_p] rstd (optional)
   float* lds = lds_all + a.nrm_floats;          // halo patch [180][S]
@@ -50,7 +58,7 @@ __global__ __launch_bounds__(256) void deconv4_fused_kernel(const ConvArgs a) {
 #pragma unroll
   for (int mr = 0; mr < MR; ++mr) {
     const int p = (wave * MR + mr) * 16 + mrow;
-    abase[mr] = ((p / kDTX) * kDPX + p % kDTX) * S2 + kq;
+    abase[mr] = ((p / kDTX) * kDPX + p % kDTX) * S2 + kq * 2;          // (float2 units, 16-byte aligned)
   }
   f32x4 acc[MR][NR];                            // [row block][parity * NRP + column block]
 #pragma unroll
@@ -70,10 +78,10 @@ __global__ __launch_bounds__(256) void deconv4_fused_kernel(const ConvArgs a) {
   }
   const float* __restrict__ xin = a.x + (size_t)n * a.Hin * a.Win * a.in_px;
   const int nkc8_total = a.cin_p >> 3;
-  const float2* __restrict__ wbase = reinterpret_cast<const float2*>(a.w);
+  const float4* __restrict__ wbase = reinterpret_cast<const float4*>(a.w);
   const unsigned ulane = lane;
-  const int tap_stride = nkc8_total * NRP * 64;            // float2 units (launcher: cout_p16 = 16 NRP)
-  const int phase_stride2 = (int)(a.phase_stride >> 1);
+  const int tap_stride = (nkc8_total >> 1) * NRP * 64;     // float4 units (launcher: cout_p16 = 16 NRP)
+  const int phase_stride4 = (int)(a.phase_stride >> 2);
 
   // staging: as the PF kernels of conv_mfma.h (items addressed once, zero padding = out-of-range
   // buffer loads, the next channel pass's loads in flight under this pass's MFMAs)
@@ -132,9 +140,11 @@ __global__ __launch_bounds__(256) void deconv4_fused_kernel(const ConvArgs a) {
               }
               v.x *= m; v.y *= m; v.z *= m; v.w *= m;
             }
-            float2* dst = lds2 + pix * S2 + c4 * 2;
+            // quad c4 = channels of step c4 / 2, lane quarters 2 (c4 & 1) and + 1; slot of
+            // (step, quarter) inside its 16-channel pair: quarter * 2 + step parity
+            float2* dst = lds2 + pix * S2 + (c4 >> 2) * 8 + (c4 & 1) * 4 + ((c4 >> 1) & 1);
             dst[0] = make_float2(v.x, v.y);
-            dst[1] = make_float2(v.z, v.w);
+            dst[2] = make_float2(v.z, v.w);
           }
         }
       };
@@ -146,12 +156,12 @@ __global__ __launch_bounds__(256) void deconv4_fused_kernel(const ConvArgs a) {
     __syncthreads();
     if (c0 + KC < a.cin_p) issue_pf(c0 + KC);
 
-    int koff[KC8];
+    int koff[KP];
 #pragma unroll
-    for (int k8 = 0; k8 < KC8; ++k8) koff[k8] = min((c0 >> 3) + k8, nkc8_total - 1) * NRP * 64;
+    for (int k8 = 0; k8 < KP; ++k8) koff[k8] = min((c0 >> 4) + k8, (nkc8_total >> 1) - 1) * NRP * 64;
     // the 16 (window position, parity) groups in window order; the weights of group g + 1 are
     // requested before the MFMAs of group g
-    auto wptr = [&](int g) __attribute__((always_inline)) -> const float2* {
+    auto wptr = [&](int g) __attribute__((always_inline)) -> const float4* {
       // g -> (r, s, py, px) by enumeration (compile-time after unrolling)
       int idx = 0;
       for (int r = 0; r < 3; ++r)
@@ -160,7 +170,7 @@ __global__ __launch_bounds__(256) void deconv4_fused_kernel(const ConvArgs a) {
             for (int px = 0; px < 2; ++px) {
               const int ty = r - py, tx = s - px;
               if (ty < 0 || ty > 1 || tx < 0 || tx > 1) continue;
-              if (idx == g) return wbase + (size_t)(py * 2 + px) * phase_stride2 + (ty * 2 + tx) * tap_stride;
+              if (idx == g) return wbase + (size_t)(py * 2 + px) * phase_stride4 + (ty * 2 + tx) * tap_stride;
               ++idx;
             }
       return wbase;
@@ -169,36 +179,37 @@ __global__ __launch_bounds__(256) void deconv4_fused_kernel(const ConvArgs a) {
     // before its use, far less than an L2 round trip): the weights of group g + 2 and the A rows of
     // the next window position are requested BEFORE the 32 MFMAs of group g, and the scheduling
     // barriers keep them there.
-    float2 bq[3][KC8][NRP];
+    float4 bq[3][KP][NRP];
 #pragma unroll
     for (int g0 = 0; g0 < 2; ++g0) {
-      const float2* w0 = wptr(g0) + ulane;
+      const float4* w0 = wptr(g0) + ulane;
 #pragma unroll
-      for (int k8 = 0; k8 < KC8; ++k8)
+      for (int k8 = 0; k8 < KP; ++k8)
 #pragma unroll
         for (int nr = 0; nr < NRP; ++nr) bq[g0][k8][nr] = w0[koff[k8] + nr * 64];
     }
-    float2 an[KC8][MR];
+    float4 an[KP][MR];
 #pragma unroll
-    for (int k8 = 0; k8 < KC8; ++k8)
+    for (int k8 = 0; k8 < KP; ++k8)
 #pragma unroll
-      for (int mr = 0; mr < MR; ++mr) an[k8][mr] = lds2[abase[mr] + k8 * 4];
+      for (int mr = 0; mr < MR; ++mr) an[k8][mr] = *reinterpret_cast<const float4*>(lds2 + abase[mr] + k8 * 8);
     int g = 0;
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
-        float2 ac[KC8][MR];
+        float4 ac[KP][MR];
 #pragma unroll
-        for (int k8 = 0; k8 < KC8; ++k8)
+        for (int k8 = 0; k8 < KP; ++k8)
 #pragma unroll
           for (int mr = 0; mr < MR; ++mr) ac[k8][mr] = an[k8][mr];
         if (r * 3 + s + 1 < 9) {
           const int r1 = (r * 3 + s + 1) / 3, s1 = (r * 3 + s + 1) % 3;
 #pragma unroll
-          for (int k8 = 0; k8 < KC8; ++k8)
+          for (int k8 = 0; k8 < KP; ++k8)
 #pragma unroll
-            for (int mr = 0; mr < MR; ++mr) an[k8][mr] = lds2[abase[mr] + (r1 * kDPX + s1) * S2 + k8 * 4];
+            for (int mr = 0; mr < MR; ++mr)
+              an[k8][mr] = *reinterpret_cast<const float4*>(lds2 + abase[mr] + (r1 * kDPX + s1) * S2 + k8 * 8);
         }
 #pragma unroll
         for (int py = 0; py < 2; ++py)
@@ -207,28 +218,25 @@ __global__ __launch_bounds__(256) void deconv4_fused_kernel(const ConvArgs a) {
             const int ty = r - py, tx = s - px;
             if (ty < 0 || ty > 1 || tx < 0 || tx > 1) continue;
             if (g + 2 < 16) {
-              const float2* wn = wptr(g + 2) + ulane;
+              const float4* wn = wptr(g + 2) + ulane;
 #pragma unroll
-              for (int k8 = 0; k8 < KC8; ++k8)
+              for (int k8 = 0; k8 < KP; ++k8)
 #pragma unroll
                 for (int nr = 0; nr < NRP; ++nr) bq[(g + 2) % 3][k8][nr] = wn[koff[k8] + nr * 64];
             }
             __builtin_amdgcn_sched_barrier(0);
             const int ph = py * 2 + px;
 #pragma unroll
-            for (int k8 = 0; k8 < KC8; ++k8) {
-#pragma unroll
-              for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-                for (int nr = 0; nr < NRP; ++nr)
-                  acc[mr][ph * NRP + nr] = TR ? __builtin_amdgcn_mfma_f32_16x16x4f32(bq[g % 3][k8][nr].x, ac[k8][mr].x, acc[mr][ph * NRP + nr], 0, 0, 0)
-                                           : __builtin_amdgcn_mfma_f32_16x16x4f32(ac[k8][mr].x, bq[g % 3][k8][nr].x, acc[mr][ph * NRP + nr], 0, 0, 0);
-#pragma unroll
-              for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-                for (int nr = 0; nr < NRP; ++nr)
-                  acc[mr][ph * NRP + nr] = TR ? __builtin_amdgcn_mfma_f32_16x16x4f32(bq[g % 3][k8][nr].y, ac[k8][mr].y, acc[mr][ph * NRP + nr], 0, 0, 0)
-                                           : __builtin_amdgcn_mfma_f32_16x16x4f32(ac[k8][mr].y, bq[g % 3][k8][nr].y, acc[mr][ph * NRP + nr], 0, 0, 0);
+            for (int k8 = 0; k8 < KP; ++k8) {
+              // x, y: the even 8-channel step; z, w: the odd one (the order of the unpaired kernels)
+#define JH_D4_STEP(C)                                                                                          \
+  _Pragma("unroll") for (int mr = 0; mr < MR; ++mr) _Pragma("unroll") for (int nr = 0; nr < NRP; ++nr)       \
+    acc[mr][ph * NRP + nr] = TR ? __builtin_amdgcn_mfma_f32_16x16x4f32(bq[g % 3][k8][nr].C, ac[k8][mr].C,    \
+                                                                       acc[mr][ph * NRP + nr], 0, 0, 0)       \
+                                : __builtin_amdgcn_mfma_f32_16x16x4f32(ac[k8][mr].C, bq[g % 3][k8][nr].C,    \
+                                                                       acc[mr][ph * NRP + nr], 0, 0, 0);
+              JH_D4_STEP(x) JH_D4_STEP(y) JH_D4_STEP(z) JH_D4_STEP(w)
+#undef JH_D4_STEP
             }
             __builtin_amdgcn_sched_barrier(0);
             ++g;
@@ -283,13 +291,17 @@ static int launch_deconv4_inst(const ConvArgs& a, hipStream_t s) {
   return launch_deconv4_tr<NRP, KC8, false>(a, s);
 }
 
+// Layers this kernel takes (their weights are then packed in the paired layout)
+bool deconv4_eligible(int cin_p, int cout_p16) {
+  return cout_p16 <= 32 && cin_p % 16 == 0 && JH_ENV_KNOB("JH_DECONV_FUSED") != 0;
+}
+
 // Returns -1 when the layer is not this kernel's (the caller then takes the general path).
 int launch_deconv4_fused(const ConvArgs& a, hipStream_t s) {
   const int nrp = a.cout_p16 / 16;
   if (a.gate || nrp > 2 || a.nphase != 4) return -1;
-  if (JH_ENV_KNOB("JH_DECONV_FUSED") == 0) return -1;
-  const int kc8 = a.cin_p % 32 == 0 ? 4 : (a.cin_p % 24 == 0 ? 3 : (a.cin_p % 16 == 0 ? 2 : 1));
-  if (kc8 != 4 && kc8 != 2) return -1;
+  if (!a.paired) return -1;                        // (pack_conv_weights decided with deconv4_eligible)
+  const int kc8 = a.cin_p % 32 == 0 ? 4 : 2;
   if (nrp == 2 && kc8 == 4) return launch_deconv4_inst<2, 4>(a, s);
   if (nrp == 2 && kc8 == 2) return launch_deconv4_inst<2, 2>(a, s);
   if (nrp == 1 && kc8 == 4) return launch_deconv4_inst<1, 4>(a, s);

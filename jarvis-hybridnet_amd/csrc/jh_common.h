@@ -89,7 +89,8 @@ struct ConvDesc {
 
 // Packed weights of one conv (all phases), see pack_conv_weights().
 struct ConvWeights {
-  float* w = nullptr;      // [phase][tap][cin_p/8][cout_p16/16][64][2]
+  float* w = nullptr;      // [phase][tap][cin_p/8][cout_p16/16][64][2]; paired: [phase][tap][cin_p/16][cout_p16/16][64][4]
+  int paired = 0;          // two 8-channel steps per 16-byte lane word (kernels that read operands as b128)
   float* bias = nullptr;   // [cout_p16] or nullptr
   size_t phase_stride = 0; // floats
   int cin_p = 0, cout_p16 = 0;
@@ -114,6 +115,7 @@ struct ConvArgs {
   int in_px;             // floats per input pixel in memory: cin_p, or 4 for the 3-channel network
                          // input (one float4 per pixel; channels 4.. of the K padding read 0)
   int ostride, nphase;
+  int paired = 0;        // weights in the paired layout (ConvWeights::paired)
   size_t phase_stride;
   ConvPhase phase[8];
 };
