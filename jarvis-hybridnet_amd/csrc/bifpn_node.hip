@@ -18,6 +18,7 @@
 //   3. MFMA 16x16x4 fp32 over K = Cp for 4 output-channel blocks at a time
 //      (weights streamed from L2 in packed B-operand order), shared epilogue.
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 #include "conv_mfma.h"
 #include "bifpn_node.h"
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(512, 6) void bifpn_node_kernel(const NodeArgs a) {
   // items in flight per thread: 512 x 5 covers a whole 56-channel halo tile in one round
   // trip; with three inputs that costs > 80 VGPRs, i.e. the third workgroup per CU, which
   // is worth more than the single round trip
-  constexpr int U = ONE ? ((NIN == 3 || M1 == FUSE_POOL2) ? 2 : 4) : (NIN == 3 ? 3 : 5);
+  constexpr int U = ONE ? ((NIN == 3 || M1 == FUSE_POOL2) ? 2 : 6) : (NIN == 3 ? 3 : 5);
   constexpr int NT = 512;                        // threads (8 waves: latency-bound prologue)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int Cp = a.Cp;
@@ -139,11 +140,14 @@ __global__ __launch_bounds__(512, 6) void bifpn_node_kernel(const NodeArgs a) {
     int py = slot >= kNodePX ? 1 : 0;
     int px = slot - py * kNodePX;
     int pix = slot;
-    for (int p0 = 0; p0 < NPX; p0 += 32 * U) {
-      nf4 v[U][NIN];
-      float msk[U];
+    // one round = UU halo pixels per thread (32 pixel slots x UU); the 180 pixels of the tile are 4 + 2
+    // rounds of 32 for the U = 4 variants (a second round of 4 would issue two empty items)
+    auto round = [&](auto uu_c) __attribute__((always_inline)) {
+      constexpr int UU = decltype(uu_c)::value;
+      nf4 v[UU][NIN];
+      float msk[UU];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
+      for (int u = 0; u < UU; ++u) {
         const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
         const bool ok = cact && pix + u * 32 < NPX && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
         msk[u] = ok ? 1.f : 0.f;
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(512, 6) void bifpn_node_kernel(const NodeArgs a) {
         }
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
+      for (int u = 0; u < UU; ++u) {
         const int pu = pix + u * 32;
         if (pu < NPX && cact) {
           nf2 lo = bb[0], hi = bb[1];
@@ -221,7 +225,13 @@ __global__ __launch_bounds__(512, 6) void bifpn_node_kernel(const NodeArgs a) {
           *reinterpret_cast<float4*>(Ft + pu * SF + c) = make_float4(lo.x, lo.y, hi.x, hi.y);
         }
       }
-      pix += 32 * U;
+      pix += 32 * UU;
+    };
+    if constexpr (U == 4) {
+      round(std::integral_constant<int, 4>{});
+      round(std::integral_constant<int, 2>{});
+    } else {
+      for (int p0 = 0; p0 < NPX; p0 += 32 * U) round(std::integral_constant<int, U>{});
     }
     __syncthreads();
     // depthwise 3x3: the kernel's on-chip floor is LDS bandwidth, and the depthwise reads were
