@@ -51,7 +51,10 @@ __device__ __forceinline__ float4 node_fetch(const float* in, int mode, int n, i
 // The resampling modes are template parameters: with them known at compile time the
 // halo loads of several items can be issued back to back (no data-dependent branches),
 // which is what hides the HBM latency of this otherwise latency-bound prologue.
-template <int NIN, int M0, int M1, int M2, bool ONE>
+// CP: channel count known at compile time (0 = run-time a.Cp).  PMC on the run-time form: the 56 MFMAs of
+// a wave came with 147 other vector and 102 scalar instructions of address arithmetic and loop control
+// (operand offsets are multiples of Cp); with CP they are immediates of fully unrolled loops.
+template <int NIN, int M0, int M1, int M2, bool ONE, int CP = 0>
 __global__ __launch_bounds__(512, 6) void bifpn_node_kernel(const NodeArgs a) {
   constexpr int kModes[3] = {M0, M1, M2};
   // items in flight per thread: 512 x 5 covers a whole 56-channel halo tile in one round
@@ -60,9 +63,9 @@ __global__ __launch_bounds__(512, 6) void bifpn_node_kernel(const NodeArgs a) {
   constexpr int U = ONE ? ((NIN == 3 || M1 == FUSE_POOL2) ? 2 : 6) : (NIN == 3 ? 3 : 5);
   constexpr int NT = 512;                        // threads (8 waves: latency-bound prologue)
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int Cp = a.Cp;
+  const int Cp = CP ? CP : a.Cp;
   const int SA = Cp + 4;                         // operand tile stride (floats): b64 reads conflict-free
-  const int SF = a.cf;                           // halo tile stride: unpadded, so that consecutive
+  const int SF = CP ? CP : a.cf;                 // halo tile stride: unpadded, so that consecutive
                                                  // lanes touch consecutive 16-byte words
   float* mr_ = lds;                              // [3][Cp] mean, then [3][Cp] rstd
   float* dwl = mr_ + 3 * Cp * 2;                 // [9][Cp] depthwise weights
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(512, 6) void bifpn_node_kernel(const NodeArgs a) {
   const int n = bid.y;
   const int oy0 = tile_y * kNodeTY, ox0 = tile_x * kNodeTX;
 
-  const int nk8 = Cp >> 3, nb = a.cout_p16 >> 4;
+  const int nk8 = Cp >> 3, nb = CP ? kNodeNRG : (a.cout_p16 >> 4);      // (CP: the launcher checks cout_p16)
   const float2* wl = reinterpret_cast<const float2*>(a.pw) + lane;
   if (a.abl & 16) {             // experiment: de-phase the first generation of workgroups
     const unsigned L = blockIdx.x + gridDim.x * blockIdx.y;
@@ -410,7 +413,22 @@ __global__ __launch_bounds__(512, 6) void bifpn_node_kernel(const NodeArgs a) {
     int boff[kNodeNRG];
 #pragma unroll
     for (int nr = 0; nr < kNodeNRG; ++nr) boff[nr] = min(nb0 + nr, nb - 1) * 64;
-    if (a.blds) {
+    if (CP != 0) {                                // (implies a.blds)
+      const float2* B2 = reinterpret_cast<const float2*>(Bl) + lane;
+#pragma unroll
+      for (int k8 = 0; k8 < (CP >> 3); ++k8) {
+        const float2 ac = A2[abase + k8 * 4];
+        float2 bc[kNodeNRG];
+#pragma unroll
+        for (int nr = 0; nr < kNodeNRG; ++nr) bc[nr] = B2[(k8 * kNodeNRG + nr) * 64];
+#pragma unroll
+        for (int nr = 0; nr < kNodeNRG; ++nr)
+          acc[0][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac.x, bc[nr].x, acc[0][nr], 0, 0, 0);
+#pragma unroll
+        for (int nr = 0; nr < kNodeNRG; ++nr)
+          acc[0][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac.y, bc[nr].y, acc[0][nr], 0, 0, 0);
+      }
+    } else if (a.blds) {
       const float2* B2 = reinterpret_cast<const float2*>(Bl) + lane;
 #pragma unroll 1
       for (int k8 = 0; k8 < nk8; ++k8) {
@@ -455,9 +473,9 @@ __global__ __launch_bounds__(512, 6) void bifpn_node_kernel(const NodeArgs a) {
   }
 }
 
-template <int NIN, int M0, int M1, int M2, bool ONE>
+template <int NIN, int M0, int M1, int M2, bool ONE, int CP = 0>
 static int launch_node_one(const NodeArgs& a, size_t lds, hipStream_t s) {
-  auto kern = bifpn_node_kernel<NIN, M0, M1, M2, ONE>;
+  auto kern = bifpn_node_kernel<NIN, M0, M1, M2, ONE, CP>;
   static bool big = false;
   if (lds > 64 * 1024 && !big) {
     JH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -472,6 +490,9 @@ static int launch_node_one(const NodeArgs& a, size_t lds, hipStream_t s) {
 
 template <int NIN, int M0, int M1, int M2>
 static int launch_node_variant(const NodeArgs& a, size_t lds, hipStream_t s) {
+  // the small model's pyramid (56 channels, one MFMA group of 4 column blocks, weights in LDS)
+  if (a.alias && a.blds && a.Cp == 56 && a.cf == 56 && a.cout_p16 == 16 * kNodeNRG && JH_ENV_KNOB("JH_NODE_CP") != 0)
+    return launch_node_one<NIN, M0, M1, M2, true, 56>(a, lds, s);
   if (a.alias) return launch_node_one<NIN, M0, M1, M2, true>(a, lds, s);
   return launch_node_one<NIN, M0, M1, M2, false>(a, lds, s);
 }

@@ -92,6 +92,46 @@ def test_deconv2d_k4s2p1(cin, cout, H, W, bias, norm_act):
     assert e < (2e-4 if norm_act >= 0 else 2e-5)
 
 
+CONV3D = [  # k, stride, pad, cin, cout, G, norm_act
+    (3, 1, 1, 46, 46, 16, 1), (3, 2, 1, 23, 46, 24, 1), (2, 2, 0, 46, 92, 16, 1), (3, 1, 1, 92, 92, 8, -1),
+    (1, 1, 0, 46, 23, 12, -1), (3, 1, 1, 6, 6, 10, -1),
+]
+
+
+@pytest.mark.parametrize("k,stride,pad,cin,cout,G,norm_act", CONV3D)
+def test_conv3d(k, stride, pad, cin, cout, G, norm_act):
+    g = torch.Generator().manual_seed(k * 10 + cin)
+    x = torch.randn(2, cin, G, G, G, generator=g)
+    w = torch.randn(cout, cin, k, k, k, generator=g) / (cin * k ** 3) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    y, ref = _conv(3, 0, k, stride, pad, cin, cout, x, w, b, norm_act=norm_act)
+    e = rel_err(y, ref)
+    report("conv3d", k=k, stride=stride, cin=cin, cout=cout, rel=e)
+    assert e < (2e-4 if norm_act >= 0 else 2e-5)
+
+
+@pytest.mark.parametrize("cin,cout,D,H,W", [(46, 46, 16, 16, 16), (92, 92, 8, 12, 20), (6, 23, 5, 9, 11)])
+def test_conv3d_winograd_equals_direct(cin, cout, D, H, W, monkeypatch):
+    """The 3x3x3 stride-1 convs run as Winograd F(2x2,3x3) x direct z by default
+    (csrc/conv3d_wino.hip); JH_WINO=0 selects the direct MFMA kernel.  Both must match
+    torch, on volumes that are not multiples of the 4 x 8 x 8 workgroup tile too."""
+    g = torch.Generator().manual_seed(cin + D)
+    x = torch.randn(2, cin, D, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) / (cin * 27) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    y_w, ref = _conv(3, 0, 3, 1, 1, cin, cout, x, w, b, norm_act=1)
+    monkeypatch.setenv("JH_WINO_PW", "0")          # the one-role kernel (default: persistent form,
+    y_q, _ = _conv(3, 0, 3, 1, 1, cin, cout, x, w, b, norm_act=1)   # which falls back to it here)
+    monkeypatch.delenv("JH_WINO_PW")
+    assert rel_err(y_q, ref) < 2e-4
+    monkeypatch.setenv("JH_WINO", "0")
+    y_d, _ = _conv(3, 0, 3, 1, 1, cin, cout, x, w, b, norm_act=1)
+    ew, ed = rel_err(y_w, ref), rel_err(y_d, ref)
+    report("conv3d_winograd", cin=cin, cout=cout, rel_winograd=ew, rel_direct=ed)
+    assert ew < 2e-4 and ed < 2e-4
+    assert not torch.equal(y_w, y_d), "JH_WINO had no effect"
+
+
 def test_deconv3d_k2s2():
     g = torch.Generator().manual_seed(9)
     x = torch.randn(2, 92, 8, 8, 8, generator=g)
