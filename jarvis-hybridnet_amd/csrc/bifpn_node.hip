@@ -152,7 +152,9 @@ __global__ __launch_bounds__(512, 6) void bifpn_node_kernel(const NodeArgs a) {
 #pragma unroll
       for (int u = 0; u < UU; ++u) {
         const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
-        const bool ok = cact && pix + u * 32 < NPX && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        // (unsigned compares: one test per axis; only the last item of a round can run past the tile)
+        const bool ok = cact && (u * 32 + 31 < NPX || pix + u * 32 < NPX) && (unsigned)iy < (unsigned)a.H &&
+                        (unsigned)ix < (unsigned)a.W;
         msk[u] = ok ? 1.f : 0.f;
         const unsigned oob = ok ? 0u : 0x80000000u;
 #pragma unroll

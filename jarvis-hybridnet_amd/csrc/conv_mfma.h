@@ -85,7 +85,8 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[MR][NR], const Epilog
         const int p = (wave * MR + mr) * 16 + kq * 4 + r;
         const int tx = p % TX, ty = (p / TX) % TY, tz = p / (TX * TY);
         v[r] = acc[mr][nr][r] + bv;
-        if (ch_ok && (FULL || (oz0 + tz < e.Dout && oy0 + ty < e.Hout && ox0 + tx < e.Wout))) {
+        // (FULL: no test at all -- channels past cout have zero weights and zero bias, their values are 0)
+        if (FULL || (ch_ok && oz0 + tz < e.Dout && oy0 + ty < e.Hout && ox0 + tx < e.Wout)) {
           s1 += v[r];
           s2 += v[r] * v[r];
         }
