@@ -215,19 +215,29 @@ __global__ __launch_bounds__(256) void repro_gather_kernel(
         acc[q].x += h[q][cc].x; acc[q].y += h[q][cc].y; acc[q].z += h[q][cc].z; acc[q].w += h[q][cc].w;
       }
   }
+  // mean over cameras, then the /255 of hybridnet/model.py:72: two IEEE divisions per value in the
+  // reference.  x / c is evaluated as q = x rc, r = fma(-q, c, x), q' = fma(r, rc, q) with rc = RN(1 / c):
+  // by Markstein's theorem q' = RN(x / c) whenever nothing underflows -- checked exhaustively over all
+  // 2^32 inputs for c = 3 ... 16, 18, 20, 24, 32 and 255: identical bits for every |x| >= 1e-37 (below
+  // that, where the quotient is denormal, it can differ in the last denormal bit).  3 instead of 11
+  // instructions per division; the epilogue was 21 % of the kernel's vector instructions.
   const float fc = (float)C;
+  const float rfc = __fdiv_rn(1.f, fc), r255 = __fdiv_rn(1.f, 255.f);
+  auto divc = [](float x, float c, float rc) __attribute__((always_inline)) {
+    const float q = __fmul_rn(x, rc);
+    return __fmaf_rn(__fmaf_rn(-q, c, x), rc, q);
+  };
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
     const int item = q * 64 + lane;
     const int vsrc = item / Q, quad = item % Q;
     if (wave_vox0 + vsrc < vox_end) {
       float4 r;
-      // mean over cameras, then the /255 of hybridnet/model.py:72
-      r.x = __fdiv_rn(acc[q].x, fc); r.y = __fdiv_rn(acc[q].y, fc);
-      r.z = __fdiv_rn(acc[q].z, fc); r.w = __fdiv_rn(acc[q].w, fc);
+      r.x = divc(acc[q].x, fc, rfc); r.y = divc(acc[q].y, fc, rfc);
+      r.z = divc(acc[q].z, fc, rfc); r.w = divc(acc[q].w, fc, rfc);
       if (div255) {
-        r.x = __fdiv_rn(r.x, 255.f); r.y = __fdiv_rn(r.y, 255.f);
-        r.z = __fdiv_rn(r.z, 255.f); r.w = __fdiv_rn(r.w, 255.f);
+        r.x = divc(r.x, 255.f, r255); r.y = divc(r.y, 255.f, r255);
+        r.z = divc(r.z, 255.f, r255); r.w = divc(r.w, 255.f, r255);
       }
       *reinterpret_cast<float4*>(vol + ((size_t)t * nvox + wave_vox0 + vsrc) * Jp + quad * 4) = r;
     }
