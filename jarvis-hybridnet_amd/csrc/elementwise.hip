@@ -47,8 +47,12 @@ __device__ __forceinline__ void block_channel_reduce(float4 s1, float4 s2, int n
 }
 
 // ------------------------------------------------------------------ norm_apply
+// ACT / R1 / R2 / Y are template parameters (the run-time form spent more scalar than vector
+// instructions on its per-element branches) and four pixels per thread are in flight at a time.
+// SiLU through v_exp_f32 / v_rcp_f32, as the convolutions apply it when they stage the same tensor.
+template <int ACT, bool R1, bool R2, bool Y>
 __global__ __launch_bounds__(256) void norm_apply_kernel(
-    const float* __restrict__ x, const double* __restrict__ stats, float eps, int act,
+    const float* __restrict__ x, const double* __restrict__ stats, float eps,
     const float* __restrict__ r1, const float* __restrict__ r2, float* __restrict__ y,
     double* __restrict__ pool, int P, int Cp, int ppb) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -73,28 +77,45 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(
     mean = make_float4(m[0], m[1], m[2], m[3]);
     rstd = make_float4(rs[0], rs[1], rs[2], rs[3]);
   }
-  const size_t base = (size_t)n * P * Cp;
+  const size_t base = (size_t)n * P * Cp + c4 * 4;
   const int p0 = blockIdx.x * ppb;
   const int p1 = min(P, p0 + ppb);
   float4 ps = make_float4(0, 0, 0, 0);
+  auto act1 = [](float v) __attribute__((always_inline)) {
+    if (ACT == ACT_RELU) return fmaxf(v, 0.f);
+    if (ACT == ACT_SILU) return __fdividef(v, 1.f + __expf(-v));
+    return v;
+  };
+  auto finish = [&](float4 v, float4 a1, float4 a2, size_t off) __attribute__((always_inline)) {
+    v.x = (v.x - mean.x) * rstd.x; v.y = (v.y - mean.y) * rstd.y;
+    v.z = (v.z - mean.z) * rstd.z; v.w = (v.w - mean.w) * rstd.w;
+    if (R1) { v.x += a1.x; v.y += a1.y; v.z += a1.z; v.w += a1.w; }
+    v.x = act1(v.x); v.y = act1(v.y); v.z = act1(v.z); v.w = act1(v.w);
+    if (R2) { v.x += a2.x; v.y += a2.y; v.z += a2.z; v.w += a2.w; }
+    if (Y) *reinterpret_cast<float4*>(y + off) = v;         // !Y: pooled sums only
+    ps.x += v.x; ps.y += v.y; ps.z += v.z; ps.w += v.w;
+  };
   if (active) {
-    for (int p = p0 + row; p < p1; p += rows) {
-      const size_t off = base + (size_t)p * Cp + c4 * 4;
-      float4 v = *reinterpret_cast<const float4*>(x + off);
-      v.x = (v.x - mean.x) * rstd.x; v.y = (v.y - mean.y) * rstd.y;
-      v.z = (v.z - mean.z) * rstd.z; v.w = (v.w - mean.w) * rstd.w;
-      if (r1) {
-        const float4 a = *reinterpret_cast<const float4*>(r1 + off);
-        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    constexpr int UN = 4;
+    int p = p0 + row;
+    for (; p + (UN - 1) * rows < p1; p += UN * rows) {
+      float4 v[UN], a1[UN], a2[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const size_t off = base + (size_t)(p + u * rows) * Cp;
+        v[u] = *reinterpret_cast<const float4*>(x + off);
+        if (R1) a1[u] = *reinterpret_cast<const float4*>(r1 + off);
+        if (R2) a2[u] = *reinterpret_cast<const float4*>(r2 + off);
       }
-      v.x = act_apply(v.x, act); v.y = act_apply(v.y, act);
-      v.z = act_apply(v.z, act); v.w = act_apply(v.w, act);
-      if (r2) {
-        const float4 a = *reinterpret_cast<const float4*>(r2 + off);
-        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-      }
-      if (y) *reinterpret_cast<float4*>(y + off) = v;     // y == nullptr: pooled sums only
-      ps.x += v.x; ps.y += v.y; ps.z += v.z; ps.w += v.w;
+#pragma unroll
+      for (int u = 0; u < UN; ++u) finish(v[u], a1[u], a2[u], base + (size_t)(p + u * rows) * Cp);
+    }
+    for (; p < p1; p += rows) {
+      const size_t off = base + (size_t)p * Cp;
+      float4 a1 = make_float4(0, 0, 0, 0), a2 = a1;
+      if (R1) a1 = *reinterpret_cast<const float4*>(r1 + off);
+      if (R2) a2 = *reinterpret_cast<const float4*>(r2 + off);
+      finish(*reinterpret_cast<const float4*>(x + off), a1, a2, off);
     }
   }
   if (pool)
@@ -115,10 +136,19 @@ int launch_norm_apply(const Act& x, const double* stats, float eps, int act, con
   const int ppb = rows * iters;
   dim3 grid((P + ppb - 1) / ppb, x.N);
   const size_t sm = pool ? (size_t)rows * q * 4 * sizeof(float) : 0;
-  hipLaunchKernelGGL(norm_apply_kernel, grid, dim3(256), sm, s, x.p, stats, eps, act, r1, r2, y,
-                     pool, P, x.Cp, ppb);
-  JH_CHECK_HIP(hipGetLastError());
-  return 0;
+#define JH_NA(A, B1, B2, BY)                                                                              \
+  if (act == A && (r1 != nullptr) == B1 && (r2 != nullptr) == B2 && (y != nullptr) == BY) {             \
+    hipLaunchKernelGGL((norm_apply_kernel<A, B1, B2, BY>), grid, dim3(256), sm, s, x.p, stats, eps, r1, r2, y, \
+                       pool, P, x.Cp, ppb);                                                               \
+    JH_CHECK_HIP(hipGetLastError());                                                                      \
+    return 0;                                                                                             \
+  }
+#define JH_NA_ACT(A) JH_NA(A, false, false, false) JH_NA(A, false, false, true) JH_NA(A, true, false, true) \
+                     JH_NA(A, true, true, true) JH_NA(A, false, true, true)
+  JH_NA_ACT(ACT_NONE) JH_NA_ACT(ACT_RELU) JH_NA_ACT(ACT_SILU)
+#undef JH_NA_ACT
+#undef JH_NA
+  JH_REQUIRE(false, "norm_apply: residual inputs without an output tensor");
 }
 
 // --------------------------------------------------------------------- se_gate
