@@ -54,7 +54,7 @@ __device__ __forceinline__ size_t node_plane(int mode, int H, int W) {
 __device__ __forceinline__ float node_act(float v, int act) {
   // SiLU with the hardware exp2 / reciprocal (about 1e-7 relative error; the prologue is
   // instruction-bound on the IEEE expf + division otherwise)
-  if (act == ACT_SILU) return __fdividef(v, 1.f + __expf(-v));
+  if (act == ACT_SILU) return silu_fast(v);
   if (act == ACT_RELU) return fmaxf(v, 0.f);
   return v;
 }

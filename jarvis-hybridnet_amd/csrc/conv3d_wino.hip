@@ -131,8 +131,8 @@ __global__ __launch_bounds__(256, (kWTZ == 2 ? 2 : 1)) void conv3d_wino_kernel(c
           if (a.in_act == ACT_RELU) {
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
           } else if (a.in_act == ACT_SILU) {
-            v.x = __fdividef(v.x, 1.f + __expf(-v.x)); v.y = __fdividef(v.y, 1.f + __expf(-v.y));
-            v.z = __fdividef(v.z, 1.f + __expf(-v.z)); v.w = __fdividef(v.w, 1.f + __expf(-v.w));
+            v.x = silu_fast(v.x); v.y = silu_fast(v.y);
+            v.z = silu_fast(v.z); v.w = silu_fast(v.w);
           }
         }
         *reinterpret_cast<float4*>(R + idx * 4) = v;          // [pix][q] = idx order

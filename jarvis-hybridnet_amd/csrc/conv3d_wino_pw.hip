@@ -206,8 +206,8 @@ __global__ __launch_bounds__(512) void conv3d_wino_pw_kernel(const WinoArgs a, i
             hi = (f32x2){__builtin_amdgcn_fmed3f(hi.x, 0.f, M), __builtin_amdgcn_fmed3f(hi.y, 0.f, M)};
           } else {
             if (MODE == 3) {
-              lo = (f32x2){__fdividef(lo.x, 1.f + __expf(-lo.x)), __fdividef(lo.y, 1.f + __expf(-lo.y))};
-              hi = (f32x2){__fdividef(hi.x, 1.f + __expf(-hi.x)), __fdividef(hi.y, 1.f + __expf(-hi.y))};
+              lo = (f32x2){silu_fast(lo.x), silu_fast(lo.y)};
+              hi = (f32x2){silu_fast(hi.x), silu_fast(hi.y)};
             }
             const float m = (inv >> it & 1) ? 0.f : 1.f;
             lo *= (f32x2){m, m};

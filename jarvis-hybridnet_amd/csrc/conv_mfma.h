@@ -309,8 +309,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
       if (a.in_act == ACT_RELU) {
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
       } else if (a.in_act == ACT_SILU) {
-        v.x = __fdividef(v.x, 1.f + __expf(-v.x)); v.y = __fdividef(v.y, 1.f + __expf(-v.y));
-        v.z = __fdividef(v.z, 1.f + __expf(-v.z)); v.w = __fdividef(v.w, 1.f + __expf(-v.w));
+        v.x = silu_fast(v.x); v.y = silu_fast(v.y);
+        v.z = silu_fast(v.z); v.w = silu_fast(v.w);
       }
     }
     if (a.gate) {
@@ -378,8 +378,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
               if (MODE == 2) {
                 v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
               } else if (MODE == 3) {
-                v.x = __fdividef(v.x, 1.f + __expf(-v.x)); v.y = __fdividef(v.y, 1.f + __expf(-v.y));
-                v.z = __fdividef(v.z, 1.f + __expf(-v.z)); v.w = __fdividef(v.w, 1.f + __expf(-v.w));
+                v.x = silu_fast(v.x); v.y = silu_fast(v.y);
+                v.z = silu_fast(v.z); v.w = silu_fast(v.w);
               }
               v.x *= m; v.y *= m; v.z *= m; v.w *= m;
             }

@@ -87,8 +87,8 @@ __global__ __launch_bounds__(256) void deconv_c1_kernel(
             if (in_act == ACT_RELU) {
               x4.x = fmaxf(x4.x, 0.f); x4.y = fmaxf(x4.y, 0.f); x4.z = fmaxf(x4.z, 0.f); x4.w = fmaxf(x4.w, 0.f);
             } else if (in_act == ACT_SILU) {
-              x4.x = __fdividef(x4.x, 1.f + __expf(-x4.x)); x4.y = __fdividef(x4.y, 1.f + __expf(-x4.y));
-              x4.z = __fdividef(x4.z, 1.f + __expf(-x4.z)); x4.w = __fdividef(x4.w, 1.f + __expf(-x4.w));
+              x4.x = silu_fast(x4.x); x4.y = silu_fast(x4.y);
+              x4.z = silu_fast(x4.z); x4.w = silu_fast(x4.w);
             }
           }
           *reinterpret_cast<float4*>(tile + pix * S + lc4 * 4) = x4;

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(
   float4 ps = make_float4(0, 0, 0, 0);
   auto act1 = [](float v) __attribute__((always_inline)) {
     if (ACT == ACT_RELU) return fmaxf(v, 0.f);
-    if (ACT == ACT_SILU) return __fdividef(v, 1.f + __expf(-v));
+    if (ACT == ACT_SILU) return silu_fast(v);
     return v;
   };
   auto finish = [&](float4 v, float4 a1, float4 a2, size_t off) __attribute__((always_inline)) {

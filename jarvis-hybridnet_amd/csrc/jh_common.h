@@ -223,6 +223,12 @@ __device__ __forceinline__ BlockId xcd_block() {
 }
 #endif
 
+#if defined(__HIPCC__)
+// x * sigmoid(x) with the hardware exp2 and reciprocal (about 1e-7 relative error).  `__fdividef` is a
+// full IEEE division under this build's flags (v_div_scale / v_div_fmas / v_div_fixup: ten instructions).
+__device__ __forceinline__ float silu_fast(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
+#endif
+
 struct NodeArgs;
 int launch_bifpn_node(const NodeArgs& a, hipStream_t s);
 int pack_wino_weights(int cin, int cout, const float* w, const float* b, ConvWeights* out);
