@@ -238,12 +238,23 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   // never stored), so the main loop has no conditional loads
   // (uniform base + 32-bit lane offset: the loads take the SGPR-base addressing form and
   // their addresses are scalar arithmetic)
-  const float2* __restrict__ wbase = reinterpret_cast<const float2*>(a.w + (size_t)ph * a.phase_stride);
-  const unsigned ulane = lane;
   int boff[NR];
 #pragma unroll
   for (int nr = 0; nr < NR; ++nr) boff[nr] = min(nb0 + nr, nb16_total - 1) * 64;
   const int tap_stride = nkc8_total * nb16_total * 64;     // float2 units
+  // Weight loads are buffer loads: per-lane byte offset (column block, lane) in a register, the
+  // (tap, channel step) part as the SCALAR offset -- no per-load vector address arithmetic (the
+  // pointer form cost two 64-bit vector adds per load).
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.w + (size_t)ph * a.phase_stride), 0, (int)(a.phase_stride * 4), 0x00020000);
+  typedef unsigned int wu2 __attribute__((ext_vector_type(2)));
+  int wvo[NR];
+#pragma unroll
+  for (int nr = 0; nr < NR; ++nr) wvo[nr] = (boff[nr] + lane) * 8;
+  auto wload = [&](int idx2, int nr) __attribute__((always_inline)) -> float2 {   // idx2: uniform float2 index
+    const wu2 v = __builtin_amdgcn_raw_buffer_load_b64(wrs, wvo[nr], idx2 * 8, 0);
+    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+  };
 
   // Patch staging in two halves -- issue(c0): raw global loads into registers; commit(c0):
   // InstanceNorm / activation / gate, then LDS.  Kernels with small patches (PF: 1x1 convs and
@@ -335,8 +346,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         for (int k8 = 0; k8 < KC8; ++k8)
 #pragma unroll
           for (int nr = 0; nr < NR; ++nr)
-            breg[tp][k8][nr] = (wbase + ulane)[(size_t)tp * tap_stride +
-                                               min((c0 >> 3) + k8, nkc8_total - 1) * nb16_total * 64 + boff[nr]];
+            breg[tp][k8][nr] = wload(tp * tap_stride + min((c0 >> 3) + k8, nkc8_total - 1) * nb16_total * 64, nr);
     }
     __syncthreads();
     // ---- stage the halo patch: [pixel][KC] with stride S; channels past cin_p read 0
@@ -427,7 +437,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
       for (int k8 = 0; k8 < KC8; ++k8) {
 #pragma unroll
-        for (int nr = 0; nr < NR; ++nr) bn[k8][nr] = (wbase + koff[k8] + boff[nr])[ulane];
+        for (int nr = 0; nr < NR; ++nr) bn[k8][nr] = wload(koff[k8], nr);
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) an[k8][mr] = lds2[abase[mr] + k8 * 4];
       }
@@ -448,12 +458,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
             for (int nr = 0; nr < NR; ++nr) bc[k8][nr] = bn[k8][nr];
           }
           // operands of the next tap (the last tap re-requests itself: results unused)
-          const float2* wn = wbase + (size_t)min(tap + 1, G::NT - 1) * tap_stride;
+          const int wn = min(tap + 1, G::NT - 1) * tap_stride;
           const int noff = (dx + 1 < G::KW) ? row_off + (dx + 1) * S2 : next_row_off;
 #pragma unroll
           for (int k8 = 0; k8 < KC8; ++k8) {
 #pragma unroll
-            for (int nr = 0; nr < NR; ++nr) bn[k8][nr] = (wn + koff[k8] + boff[nr])[ulane];
+            for (int nr = 0; nr < NR; ++nr) bn[k8][nr] = wload(wn + koff[k8], nr);
 #pragma unroll
             for (int mr = 0; mr < MR; ++mr) an[k8][mr] = lds2[abase[mr] + noff + k8 * 4];
           }
@@ -527,7 +537,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
       for (int k8 = 0; k8 < KC8; ++k8)
 #pragma unroll
-        for (int nr = 0; nr < NR; ++nr) bn[k8][nr] = (wbase + ulane)[koff[k8] + boff[nr]];
+        for (int nr = 0; nr < NR; ++nr) bn[k8][nr] = wload(koff[k8], nr);
       int tap = 0;
       for (int dz = 0; dz < G::KD; ++dz)
         for (int dy = 0; dy < G::KH; ++dy) {
@@ -539,13 +549,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
             for (int k8 = 0; k8 < KC8; ++k8)
 #pragma unroll
               for (int mr = 0; mr < MR; ++mr) ac[k8][mr] = lds2[abase[mr] + row_off + dx * S2 + k8 * 4];
-            const float2* wn = (wbase + ulane) + (size_t)min(tap + 1, G::NT - 1) * tap_stride;
+            const int wn = min(tap + 1, G::NT - 1) * tap_stride;
 #pragma unroll
             for (int k8 = 0; k8 < KC8; ++k8)
 #pragma unroll
               for (int nr = 0; nr < NR; ++nr) {
                 bc[k8][nr] = bn[k8][nr];
-                bn[k8][nr] = wn[koff[k8] + boff[nr]];
+                bn[k8][nr] = wload(wn + koff[k8], nr);
               }
 #pragma unroll
             for (int k8 = 0; k8 < KC8; ++k8) {
