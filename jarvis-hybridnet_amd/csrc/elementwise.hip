@@ -62,21 +62,27 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(
   const bool active = tid < rows * q;
   const int c4 = tid % q, row = tid / q;
   const int n = blockIdx.y;
+  // mean / rstd: one channel per thread (the fp64 divisions and square root are ~80 instructions; every
+  // thread doing its own four channels made this prologue longer than the 8 pixels a thread then
+  // processes), shared through LDS behind the pooled-sum scratch
   float4 mean = make_float4(0, 0, 0, 0), rstd = make_float4(1, 1, 1, 1);
-  if (stats && active) {
-    float m[4], rs[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const double* st = stats + ((size_t)n * Cp + c4 * 4 + j) * kStatW;
+  if (stats) {
+    float* mr = sm + (pool ? rows * q * 4 : 0);          // [Cp] mean, [Cp] rstd
+    for (int c = tid; c < Cp; c += 256) {
+      const double* st = stats + ((size_t)n * Cp + c) * kStatW;
       const double mu = exact_read(st) / (double)P;
       double var = exact_read(st + kLimbs) / (double)P - mu * mu;
       if (var < 0.0) var = 0.0;
-      m[j] = (float)mu;
-      rs[j] = (float)(1.0 / sqrt(var + (double)eps));
+      mr[c] = (float)mu;
+      mr[Cp + c] = (float)(1.0 / sqrt(var + (double)eps));
     }
-    mean = make_float4(m[0], m[1], m[2], m[3]);
-    rstd = make_float4(rs[0], rs[1], rs[2], rs[3]);
-  }
+    __syncthreads();
+    if (active) {
+      mean = *reinterpret_cast<const float4*>(mr + c4 * 4);
+      rstd = *reinterpret_cast<const float4*>(mr + Cp + c4 * 4);
+    }
+    __syncthreads();                                     // (the pooled-sum reduce reuses nothing of mr, but
+  }                                                      //  keeps the scratch layout simple)
   const size_t base = (size_t)n * P * Cp + c4 * 4;
   const int p0 = blockIdx.x * ppb;
   const int p1 = min(P, p0 + ppb);
@@ -135,7 +141,7 @@ int launch_norm_apply(const Act& x, const double* stats, float eps, int act, con
   while ((P + rows * iters - 1) / (rows * iters) > 64 && iters < 64) iters *= 2;
   const int ppb = rows * iters;
   dim3 grid((P + ppb - 1) / ppb, x.N);
-  const size_t sm = pool ? (size_t)rows * q * 4 * sizeof(float) : 0;
+  const size_t sm = ((pool ? (size_t)rows * q * 4 : 0) + (stats ? (size_t)2 * x.Cp : 0)) * sizeof(float);
 #define JH_NA(A, B1, B2, BY)                                                                              \
   if (act == A && (r1 != nullptr) == B1 && (r2 != nullptr) == B2 && (y != nullptr) == BY) {             \
     hipLaunchKernelGGL((norm_apply_kernel<A, B1, B2, BY>), grid, dim3(256), sm, s, x.p, stats, eps, r1, r2, y, \
