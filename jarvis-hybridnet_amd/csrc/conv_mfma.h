@@ -233,14 +233,17 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   // ---- block coordinates
   const int tiles_x = (a.Wout + TX - 1) / TX;
   const int tiles_y = (a.Hout + TY - 1) / TY;
-  const BlockId bid = xcd_block();             // neighbouring tiles share an XCD's L2
-  int t = bid.x;
-  const int tile_x = t % tiles_x; t /= tiles_x;
-  const int tile_y = t % tiles_y; t /= tiles_y;
-  const int tile_z = t;
+  const BlockId bid = xcd_block(a.fgx, a.fgy);  // neighbouring tiles share an XCD's L2
+  const int t1 = (int)fd_div(bid.x, a.ftx);
+  const int tile_x = (int)bid.x - t1 * tiles_x;
+  const int tile_z = (int)fd_div((unsigned)t1, a.fty);
+  const int tile_y = t1 - tile_z * tiles_y;
   const int nb0 = bid.y * NR;
-  const int n = bid.z / a.nphase;
-  const int ph = bid.z % a.nphase;
+  int n = bid.z, ph = 0;
+  if (a.nphase > 1) {                          // (power of two: 4 or 8 phases)
+    ph = bid.z & (a.nphase - 1);
+    n = bid.z >> (a.nphase == 4 ? 2 : 3);
+  }
   const int oz0 = tile_z * TZ, oy0 = tile_y * TY, ox0 = tile_x * TX;
   const int iz0 = oz0 * STRIDE - a.phase[ph].pad[0];
   const int iy0 = oy0 * STRIDE - a.phase[ph].pad[1];
@@ -673,7 +676,11 @@ int launch_conv_inst(const ConvArgs& b, dim3 grid, hipStream_t s) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     big_lds_enabled = true;
   }
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, b);
+  ConvArgs c = b;
+  c.fgx = make_fastdiv(grid.x); c.fgy = make_fastdiv(grid.y);
+  c.ftx = make_fastdiv((b.Wout + TX - 1) / TX); c.fty = make_fastdiv((b.Hout + TY - 1) / TY);
+  JH_REQUIRE(b.nphase == 1 || b.nphase == 4 || b.nphase == 8, "phase count");
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, c);
   JH_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -96,6 +96,23 @@ struct ConvWeights {
   int cin_p = 0, cout_p16 = 0;
 };
 
+// Division of block indices by run-time extents (grid dimensions, tiles per row): the compiler's 32-bit
+// unsigned division is ~28 instructions (float reciprocal + corrections, through v_readfirstlane) and a
+// tile prologue has five of them.  Host-computed multiply-shift instead: q = (mulhi(x, mul) + x) >> shift,
+// exact for x < 2^31 (Granlund-Montgomery; mul = floor(2^32 (2^l - d) / d) + 1, l = ceil(log2 d)).
+struct FastDiv {
+  unsigned mul = 1, shift = 0, d = 1;
+};
+inline FastDiv make_fastdiv(unsigned d) {
+  FastDiv f;
+  f.d = d;
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  f.shift = l;
+  f.mul = (unsigned)((((1ull << l) - d) << 32) / d + 1);
+  return f;
+}
+
 struct ConvArgs {
   const float* x;        // input activation
   float* y;              // output activation (raw, pre-norm)
@@ -116,6 +133,7 @@ struct ConvArgs {
                          // input (one float4 per pixel; channels 4.. of the K padding read 0)
   int ostride, nphase;
   int paired = 0;        // weights in the paired layout (ConvWeights::paired)
+  FastDiv fgx, fgy, ftx, fty;   // divisors: grid x / y, tiles per row / column (set by the launcher)
   size_t phase_stride;
   ConvPhase phase[8];
 };
@@ -210,6 +228,19 @@ __device__ __forceinline__ void stat_add(double* st, float s1, float s2) {
 __device__ __forceinline__ unsigned xcd_linear(unsigned L, unsigned total) {
   const unsigned q = total >> 3, r = total & 7u, x = L & 7u, s = L >> 3;
   return x < r ? x * (q + 1) + s : r * (q + 1) + (x - r) * q + s;
+}
+__device__ __forceinline__ unsigned fd_div(unsigned x, const FastDiv& f) { return (__umulhi(x, f.mul) + x) >> f.shift; }
+// the same bijection with host-prepared divisors of gridDim.x / gridDim.y
+__device__ __forceinline__ BlockId xcd_block(const FastDiv& fgx, const FastDiv& fgy) {
+  const unsigned gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+  const unsigned L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+  const unsigned l = xcd_linear(L, gx * gy * gz);
+  BlockId b;
+  const unsigned l1 = fd_div(l, fgx);
+  b.x = l - l1 * gx;
+  b.z = fd_div(l1, fgy);
+  b.y = l1 - b.z * gy;
+  return b;
 }
 __device__ __forceinline__ BlockId xcd_block() {
   const unsigned gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
