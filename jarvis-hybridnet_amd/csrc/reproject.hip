@@ -112,7 +112,7 @@ template <int Q>
 __global__ __launch_bounds__(256) void repro_gather_kernel(
     const float2* __restrict__ coarse, const float* __restrict__ heat, float* __restrict__ vol,
     int* __restrict__ idx_out, int C, int G, int hs, int Jp, int heat_pad, int div255, int ci_n,
-    int cj_n) {
+    int cj_n, FastDiv fgh, FastDiv frows, FastDiv fcjn, FastDiv fbpp) {
   extern __shared__ __attribute__((aligned(16))) float2 ctab[];   // [C][ci_n][cj_n][Gh]
   const BlockId bid = xcd_block();             // consecutive planes share heatmap regions
   const int t = bid.y;
@@ -122,8 +122,8 @@ __global__ __launch_bounds__(256) void repro_gather_kernel(
   const int lane = tid & 63;
   // blocks never straddle an i-plane: plane p owns blocks [p*bpp, (p+1)*bpp)
   const int bpp = (G * G + 255) / 256;
-  const int plane = bid.x / bpp;
-  const int vox0 = plane * G * G + (bid.x % bpp) * 256;
+  const int plane = (int)fd_div(bid.x, fbpp);
+  const int vox0 = plane * G * G + ((int)bid.x - plane * bpp) * 256;
   const int vox_end = (plane + 1) * G * G;
   const int wave_vox0 = vox0 + (tid >> 6) * 64;
   const int vox = wave_vox0 + lane;
@@ -148,9 +148,13 @@ __global__ __launch_bounds__(256) void repro_gather_kernel(
     cj_lo = (cj_n >= Gh) ? 0 : a0;
   }
   const int rows = ci_n * cj_n;
+  // (index arithmetic through host-prepared multiply-shifts: the three run-time divisions per element
+  // of this loop were a quarter of the kernel's vector instructions)
   for (int idx = tid; idx < C * rows * Gh; idx += 256) {
-    const int ck = idx % Gh, r = (idx / Gh) % rows, c = idx / (Gh * rows);
-    const int ci = min(ci_lo + r / cj_n, Gh - 1), cj = min(cj_lo + r % cj_n, Gh - 1);
+    const int q1 = (int)fd_div((unsigned)idx, fgh), ck = idx - q1 * Gh;
+    const int c = (int)fd_div((unsigned)q1, frows), r = q1 - c * rows;
+    const int ri = (int)fd_div((unsigned)r, fcjn), rj = r - ri * cj_n;
+    const int ci = min(ci_lo + ri, Gh - 1), cj = min(cj_lo + rj, Gh - 1);
     ctab[idx] = coarse[(size_t)(t * C + c) * nvox_c + (ci * Gh + cj) * Gh + ck];
   }
   const int r00 = ((i0 - ci_lo) * cj_n + (j0 - cj_lo)) * Gh, r01 = ((i0 - ci_lo) * cj_n + (j1 - cj_lo)) * Gh;
@@ -267,7 +271,8 @@ int launch_reproject(const float* cam, const float* intr, const float* dist, con
 #define JH_RG(QV)                                                                              \
   case QV:                                                                                     \
     hipLaunchKernelGGL(repro_gather_kernel<QV>, grid, dim3(256), lds, s, coarse, heat, vol,    \
-                       idx_out, C, G, hs, Jp, heat_pad, div255, ci_n, cj_n);                  \
+                       idx_out, C, G, hs, Jp, heat_pad, div255, ci_n, cj_n, make_fastdiv(Gh),   \
+                       make_fastdiv(ci_n * cj_n), make_fastdiv(cj_n), make_fastdiv(bpp));      \
     break;
   switch (Jp / 4) {
     JH_RG(2) JH_RG(4) JH_RG(6) JH_RG(8) JH_RG(10) JH_RG(12) JH_RG(14) JH_RG(16)
