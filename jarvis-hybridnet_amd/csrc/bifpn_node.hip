@@ -406,9 +406,7 @@ __global__ __launch_bounds__(512, 6) void bifpn_node_kernel(const NodeArgs a) {
   e.bias = a.bias;
   e.stats = a.stats ? a.stats + (size_t)n * a.cout_p * kStatW : nullptr;
   e.Dout = 1; e.Hout = a.H; e.Wout = a.W; e.Hy = a.H; e.Wy = a.W;
-  const long ybytes = (long)a.H * a.W * a.cout_p * 4;
-  e.ybytes = ybytes < (1L << 31) ? (int)ybytes : 0;
-  const bool full_tile = e.ybytes && oy0 + kNodeTY <= a.H && ox0 + kNodeTX <= a.W;      // (uniform)
+  const bool full_tile = oy0 + kNodeTY <= a.H && ox0 + kNodeTX <= a.W;      // (uniform)
   e.cout_p = a.cout_p; e.cout_p16 = a.cout_p16; e.os = 1; e.osz = 1; e.offz = e.offy = e.offx = 0;
   for (int nb0 = 0; nb0 < nb; nb0 += kNodeNRG) {
     f32x4 acc[1][kNodeNRG];

@@ -50,8 +50,6 @@ struct EpilogueArgs {
   double* stats;         // statistics row of image n, or nullptr
   int Dout, Hout, Wout, Hy, Wy, cout_p, cout_p16, os, offz, offy, offx;
   int osz;               // output stride along z (= os except for the (y, x)-only phases of conv3d_wino)
-  int ybytes = 0;        // bytes of image n's output when < 2^31 (FULL epilogues store through a buffer
-                         // descriptor: callers pass FULL only when this is set)
 };
 
 // Shared epilogue of the MFMA kernels: bias, store of the raw output, and the
@@ -73,24 +71,6 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[MR][NR], const Epilog
                                               int tid) {
   const int lane = tid & 63, wave = tid >> 6, mrow = lane & 15, kq = lane >> 4;
   const int j = lane & 3;                  // position inside the lane quad
-  // FULL tiles store through a buffer descriptor of the image: the per-lane part of the address
-  // (pixel kq * 4 + j of a 16-pixel row block, channel quad) is computed ONCE, the row block and
-  // the column block go into the scalar offset, and lanes whose channel quad lies past the tensor
-  // get an out-of-range offset (the store is dropped) instead of a branch.  The pointer form cost
-  // ~30 vector instructions of 64-bit address arithmetic and predicates per 16 x 16 block.
-  constexpr bool BUFST = FULL && (16 % TX == 0) && (TY % (16 / TX) == 0);
-  __amdgpu_buffer_rsrc_t yrs;
-  int voff[NR];
-  const int uwave = __builtin_amdgcn_readfirstlane(wave);
-  if constexpr (BUFST) {
-    yrs = __builtin_amdgcn_make_buffer_rsrc(e.y, 0, e.ybytes, 0x00020000);
-    const int L = kq * 4 + j;
-    const int lpix = ((L / TX) * e.os) * e.Wy + (L % TX) * e.os;
-    const int lane_off = (lpix * e.cout_p + (mrow & ~3)) * 4;
-#pragma unroll
-    for (int nr = 0; nr < NR; ++nr)
-      voff[nr] = ((nb0 + nr) * 16 + (mrow & ~3) < e.cout_p) ? lane_off : (int)0x80000000;
-  }
 #pragma unroll
   for (int nr = 0; nr < NR; ++nr) {
     const int ch = (nb0 + nr) * 16 + mrow;
@@ -121,15 +101,6 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[MR][NR], const Epilog
         x = (j & 2) ? v[0] : v[2]; y = quad_xor2(x); if (j & 2) v[0] = y; else v[2] = y;
         x = (j & 2) ? v[1] : v[3]; y = quad_xor2(x); if (j & 2) v[1] = y; else v[3] = y;
       }
-      if constexpr (BUFST) {
-        // uniform part of the address (row block of this wave, column block) as the scalar offset
-        const int U = uwave * MR + mr;
-        const int tyU = (U * (16 / TX)) % TY, tzU = (U * (16 / TX)) / TY;
-        const int upix = (((oz0 + tzU) * e.osz + e.offz) * e.Hy + ((oy0 + tyU) * e.os + e.offy)) * e.Wy + ox0 * e.os + e.offx;
-        typedef unsigned int eu4 __attribute__((ext_vector_type(4)));
-        const eu4 d = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-        __builtin_amdgcn_raw_buffer_store_b128(d, yrs, voff[nr], (upix * e.cout_p + (nb0 + nr) * 16) * 4, 0);
-      } else {
       const int p = (wave * MR + mr) * 16 + kq * 4 + j;
       const int tx = p % TX, ty = (p / TX) % TY, tz = p / (TX * TY);
       const int oz = oz0 + tz, oy = oy0 + ty, ox = ox0 + tx;
@@ -138,7 +109,6 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[MR][NR], const Epilog
         *reinterpret_cast<float4*>(
             e.y + ((size_t)((oz * e.osz + e.offz) * e.Hy + (oy * e.os + e.offy)) * e.Wy + (ox * e.os + e.offx)) * e.cout_p + c0) =
             make_float4(v[0], v[1], v[2], v[3]);
-      }
     }
     if (e.stats) {
       s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
@@ -176,14 +146,6 @@ template <int MR, int NR, int TY, int TX, bool FULL>
 __device__ __forceinline__ void conv_epilogue_tr(f32x4 (&acc)[MR][NR], const EpilogueArgs& e, int nb0,
                                                  int oz0, int oy0, int ox0, int tid) {
   const int lane = tid & 63, wave = tid >> 6, mrow = lane & 15, kq = lane >> 4;
-  constexpr bool BUFST = FULL && (16 % TX == 0) && (TY % (16 / TX) == 0);     // (see conv_epilogue)
-  __amdgpu_buffer_rsrc_t yrs;
-  int lane_off = 0;
-  const int uwave = __builtin_amdgcn_readfirstlane(wave);
-  if constexpr (BUFST) {
-    yrs = __builtin_amdgcn_make_buffer_rsrc(e.y, 0, e.ybytes, 0x00020000);
-    lane_off = ((((mrow / TX) * e.os) * e.Wy + (mrow % TX) * e.os) * e.cout_p + kq * 4) * 4;
-  }
 #pragma unroll
   for (int nr = 0; nr < NR; ++nr) {
     const int c0 = (nb0 + nr) * 16 + kq * 4;
@@ -191,19 +153,10 @@ __device__ __forceinline__ void conv_epilogue_tr(f32x4 (&acc)[MR][NR], const Epi
     if (e.bias && c0 < e.cout_p16) bv = *reinterpret_cast<const f32x4*>(e.bias + c0);
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) {
-      const f32x4 v = acc[mr][nr] + bv;
-      if constexpr (BUFST) {
-        const int U = uwave * MR + mr;
-        const int tyU = (U * (16 / TX)) % TY, tzU = (U * (16 / TX)) / TY;
-        const int upix = (((oz0 + tzU) * e.osz + e.offz) * e.Hy + ((oy0 + tyU) * e.os + e.offy)) * e.Wy + ox0 * e.os + e.offx;
-        typedef unsigned int eu4 __attribute__((ext_vector_type(4)));
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(eu4, v), yrs, c0 < e.cout_p ? lane_off : (int)0x80000000,
-                                               (upix * e.cout_p + (nb0 + nr) * 16) * 4, 0);
-        continue;
-      }
       const int p = (wave * MR + mr) * 16 + mrow;
       const int tx = p % TX, ty = (p / TX) % TY, tz = p / (TX * TY);
       const int oz = oz0 + tz, oy = oy0 + ty, ox = ox0 + tx;
+      const f32x4 v = acc[mr][nr] + bv;
       if (c0 < e.cout_p && (FULL || (oz < e.Dout && oy < e.Hout && ox < e.Wout)))
         *reinterpret_cast<f32x4*>(
             e.y + ((size_t)((oz * e.osz + e.offz) * e.Hy + (oy * e.os + e.offy)) * e.Wy + (ox * e.os + e.offx)) * e.cout_p + c0) = v;
@@ -637,9 +590,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   // tiles entirely inside the output (all of them when the extents are multiples of the tile)
   // take the epilogue without per-value bounds checks: with them every one of the 4 MR NR values
   // of a lane costs an exec-masked block of a dozen instructions
-  const long ybytes = (long)a.Dy * a.Hy * a.Wy * a.cout_p * 4;
-  e.ybytes = ybytes < (1L << 31) ? (int)ybytes : 0;
-  if (e.ybytes && oz0 + TZ <= a.Dout && oy0 + TY <= a.Hout && ox0 + TX <= a.Wout)
+  if (oz0 + TZ <= a.Dout && oy0 + TY <= a.Hout && ox0 + TX <= a.Wout)
     conv_epilogue<MR, NR, TY, TX, 4, true>(acc, e, lds, nb0, oz0, oy0, ox0, tid);
   else
     conv_epilogue<MR, NR, TY, TX>(acc, e, lds, nb0, oz0, oy0, ox0, tid);

@@ -252,9 +252,7 @@ __global__ __launch_bounds__(256) void deconv4_fused_kernel(const ConvArgs a) {
   e.stats = a.stats ? a.stats + (size_t)n * a.cout_p * kStatW : nullptr;
   e.Dout = 1; e.Hout = a.Hin; e.Wout = a.Win; e.Hy = a.Hy; e.Wy = a.Wy;
   e.cout_p = a.cout_p; e.cout_p16 = a.cout_p16; e.os = 2; e.osz = 2; e.offz = 0;
-  const long ybytes = (long)a.Hy * a.Wy * a.cout_p * 4;
-  e.ybytes = ybytes < (1L << 31) ? (int)ybytes : 0;
-  const bool full = e.ybytes && oy0 + kDTY <= a.Hin && ox0 + kDTX <= a.Win;
+  const bool full = oy0 + kDTY <= a.Hin && ox0 + kDTX <= a.Win;
 #pragma unroll
   for (int ph = 0; ph < 4; ++ph) {
     f32x4 pa[MR][NRP];
