@@ -72,18 +72,22 @@ def test_conv2d_gate():
     assert e < 2e-5
 
 
-@pytest.mark.parametrize("cin,cout,H,W,bias,norm_act", [
+@pytest.mark.parametrize("case", [
     (64, 23, 24, 24, False, -1),     # the keypoint head: swapped-operand epilogue (no statistics)
     (64, 23, 24, 24, True, 2),       # + bias, fused statistics -> InstanceNorm + SiLU after it
     (32, 8, 20, 12, True, -1),       # one column block per parity, ragged tiles
     (16, 23, 8, 16, False, 0),       # 16-channel passes
     (88, 23, 12, 12, False, -1),     # no instantiation of the fused kernel: four-phase general path
+    (64, 23, 64, 64, False, 2, 12),  # more workgroups than CUs (a store-data hazard of an earlier epilogue
+    (64, 23, 64, 64, False, -1, 12), # only showed with two workgroups resident per CU)
 ])
-def test_deconv2d_k4s2p1(cin, cout, H, W, bias, norm_act):
+def test_deconv2d_k4s2p1(case):
+    cin, cout, H, W, bias, norm_act = case[:6]
+    n = case[6] if len(case) > 6 else 2
     """ConvTranspose2d(k4, s2, p1): csrc/deconv4.hip (all four output parities from one staged patch)
     and the four-phase form of conv_mfma.h, against torch."""
     g = torch.Generator().manual_seed(8 + cin + H)
-    x = torch.randn(2, cin, H, W, generator=g)
+    x = torch.randn(n, cin, H, W, generator=g)
     w = torch.randn(cin, cout, 4, 4, generator=g) / (cin * 4) ** 0.5    # asymmetric: catches tap/phase swaps
     b = torch.randn(cout, generator=g) * 0.3 if bias else None
     y, ref = _conv(2, 1, 4, 2, 1, cin, cout, x, w, b, norm_act=norm_act)
