@@ -98,6 +98,34 @@ def test_predictor3d_time_batch():
             assert torch.equal(pts[t], p[0]) and torch.equal(conf[t], q[0])
 
 
+def test_time_batch_at_bench_scale():
+    """16 frame sets of configs[2] in one call (192 images per 2D network launch: several workgroups
+    resident per CU, thousands per launch -- the regime bench.py runs in) give, frame by frame, the bits of
+    the single-frame call.  Guards against occupancy-dependent faults that the small cases cannot show
+    (a store-data hazard of a reverted epilogue only appeared with two workgroups per CU)."""
+    from jarvis_hybridnet_amd._predictor import NativePredictor
+    from jarvis_hybridnet_amd import synthetic as S
+    c = cases.PREDICTOR_CASES["cfg3"]
+    inp = cases.predictor_inputs("cfg3")
+    T = 16
+    kw = dict(num_cameras=c["C"], num_joints=c["J"], center_size=c["center_size"], bbox=c["bbox"],
+              roi_cube_size=c["roi"], grid_spacing=c["spacing"], img_h=c["H"], img_w=c["W"],
+              mean=S.MEAN, std=S.STD)
+    dev = [cuda(t) for t in (inp["cam"], inp["intr"], inp["dist"])]
+    one = cuda(inp["imgs"]).unsqueeze(0).contiguous()
+    p1 = NativePredictor(inp["sd_center"], inp["sd_hybrid"], time_batch=1, **kw)
+    p1.set_calibration(*dev)
+    ref = [t.clone() for t in p1.forward(one)]
+    pT = NativePredictor(inp["sd_center"], inp["sd_hybrid"], time_batch=T, **kw)
+    pT.set_calibration(*dev)
+    frames = one.expand(T, *one.shape[1:]).contiguous()
+    for _ in range(2):
+        out = [t.clone() for t in pT.forward(frames)]
+        torch.cuda.synchronize()
+        for t in range(T):
+            assert torch.equal(out[0][t], ref[0][0]) and torch.equal(out[1][t], ref[1][0]), t
+
+
 def test_sharded_stages_emulated_two_ranks():
     """The camera-sharded stage API on ONE GPU: two NativePredictors own half of
     the cameras each, the two exchanges of distributed.py are done by hand
