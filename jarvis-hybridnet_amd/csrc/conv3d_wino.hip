@@ -286,8 +286,8 @@ __global__ __launch_bounds__(256, (kWTZ == 2 ? 2 : 1)) void conv3d_wino_kernel(c
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr) {
       float t1 = s1[nr], t2 = s2[nr];
-      t1 += __shfl_xor(t1, 16); t2 += __shfl_xor(t2, 16);
-      t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);
+      t1 = sum_xor16(t1); t2 = sum_xor16(t2);
+      t1 = sum_xor32(t1); t2 = sum_xor32(t2);
       if (kq == 0) {
         X[(wave * NR * 16 + nr * 16 + mrow) * 2 + 0] = t1;
         X[(wave * NR * 16 + nr * 16 + mrow) * 2 + 1] = t2;

@@ -322,8 +322,8 @@ __global__ __launch_bounds__(512) void conv3d_wino_pw_kernel(const WinoArgs a, i
         }
         if (ox == 1 && a.stats) {
           float t1 = s1[nr], t2 = s2[nr];
-          t1 += __shfl_xor(t1, 16); t2 += __shfl_xor(t2, 16);
-          t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);
+          t1 = sum_xor16(t1); t2 = sum_xor16(t2);
+          t1 = sum_xor32(t1); t2 = sum_xor32(t2);
           if (kq == 0) {
             S[(sw * NR * 16 + nr * 16 + mrow) * 2 + 0] = t1;
             S[(sw * NR * 16 + nr * 16 + mrow) * 2 + 1] = t2;

@@ -111,8 +111,8 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[MR][NR], const Epilog
             make_float4(v[0], v[1], v[2], v[3]);
     }
     if (e.stats) {
-      s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
-      s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+      s1 = sum_xor16(s1); s2 = sum_xor16(s2);
+      s1 = sum_xor32(s1); s2 = sum_xor32(s2);
       if (kq == 0) {
         red[(wave * NR * 16 + nr * 16 + mrow) * 2 + 0] = s1;
         red[(wave * NR * 16 + nr * 16 + mrow) * 2 + 1] = s2;

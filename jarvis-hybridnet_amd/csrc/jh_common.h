@@ -255,6 +255,17 @@ __device__ __forceinline__ BlockId xcd_block() {
 #endif
 
 #if defined(__HIPCC__)
+// s + (s of the lane 16 / 32 away): the two cross-row steps of a wave-wide butterfly sum through
+// v_permlane16_swap / v_permlane32_swap (gfx950) instead of ds_bpermute (an LDS instruction each).
+// Same two addends as `s + __shfl_xor(s, 16)`: bit-identical.
+__device__ __forceinline__ float sum_xor16(float s) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float sum_xor32(float s) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 // x * sigmoid(x) with the hardware exp2 and reciprocal (about 1e-7 relative error).  `__fdividef` is a
 // full IEEE division under this build's flags (v_div_scale / v_div_fmas / v_div_fixup: ten instructions).
 __device__ __forceinline__ float silu_fast(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
