@@ -127,8 +127,10 @@ __global__ __launch_bounds__(512, 6) void bifpn_node_kernel(const NodeArgs a) {
     // (q = 14 for the 56-channel pyramid)
     const int q = Cp >> 2;
     const int c4 = tid & 15, slot = tid >> 4;
-    const bool cact = c4 < q;
-    const int c = c4 * 4;
+    // lanes past the last channel quad (2 of every 16 for the 56-channel pyramid) repeat the last quad:
+    // identical values to identical addresses, and no per-item exec masking
+    constexpr bool cact = true;
+    const int c = min(c4, q - 1) * 4;
     constexpr int NPX = kNodePY * kNodePX;
     typedef float nf2 __attribute__((ext_vector_type(2)));
     typedef float nf4 __attribute__((ext_vector_type(4)));
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(512, 6) void bifpn_node_kernel(const NodeArgs a) {
 #pragma unroll
       for (int u = 0; u < UU; ++u) {
         const int pu = pix + u * 32;
-        if (pu < NPX && cact) {
+        if (u * 32 + 31 < NPX || pu < NPX) {
           nf2 lo = bb[0], hi = bb[1];
 #pragma unroll
           for (int k = 0; k < NIN; ++k) {
