@@ -29,7 +29,6 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
                                                         float* __restrict__ y, double* __restrict__ stats,
                                                         int H, int W) {
   __shared__ __attribute__((aligned(16))) float4 patch[kStP * kStP];
-  __shared__ __attribute__((aligned(16))) float wl[27 * 16];
   __shared__ float red[16 * 256];                    // statistics: [channel][thread]
   __shared__ float red2[2 * 16 * 16];
   const int tid = threadIdx.x;
@@ -38,7 +37,6 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
   const BlockId bid = xcd_block();
   const int oy0 = (bid.x / tiles_x) * kStT, ox0 = (bid.x % tiles_x) * kStT;
   const int n = bid.y;
-  for (int i = tid; i < 27 * 16; i += 256) wl[i] = w[i];
   // input patch: rows 2 oy0 - 1 .. 2 oy0 + 31, same in x
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(x + (size_t)n * H * W * 4), 0, H * W * 16, 0x00020000);
@@ -63,11 +61,13 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
       const float iv[3] = {in.x, in.y, in.z};
 #pragma unroll
       for (int ci = 0; ci < 3; ++ci) {
-        const float4* wq = reinterpret_cast<const float4*>(wl + ((ky * 3 + kx) * 3 + ci) * 16);
+        // (uniform address: the weights come through the scalar cache into SGPRs, not as 108 LDS
+        //  broadcast reads per thread -- the kernel was LDS-bandwidth-bound on them)
+        const float4* wq = reinterpret_cast<const float4*>(w + ((ky * 3 + kx) * 3 + ci) * 16);
         const sf2 xv = (sf2){iv[ci], iv[ci]};
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
-          const float4 wv = wq[q4];                  // (same address in every lane: broadcast)
+          const float4 wv = wq[q4];
           acc[q4 * 2 + 0] = __builtin_elementwise_fma(xv, (sf2){wv.x, wv.y}, acc[q4 * 2 + 0]);
           acc[q4 * 2 + 1] = __builtin_elementwise_fma(xv, (sf2){wv.z, wv.w}, acc[q4 * 2 + 1]);
         }
