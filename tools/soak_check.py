@@ -1,0 +1,42 @@
+"""Soak check at the bench's scale: a time batch of 32 frame sets of configs[2] (384 images per 2D launch)
+run repeatedly on three concurrent streams; every run of every stream must reproduce the first bit for bit,
+and every frame of the batch must equal the single-frame result."""
+import os, sys
+sys.path.insert(0, os.getcwd())
+import torch
+from jarvis_hybridnet_amd import synthetic as S
+from jarvis_hybridnet_amd._predictor import NativePredictor
+from tests import cases
+
+c = cases.PREDICTOR_CASES["cfg3"]
+inp = cases.predictor_inputs("cfg3")
+T, REPS, STREAMS = 32, int(os.environ.get("REPS", "20")), 3
+kw = dict(num_cameras=c["C"], num_joints=c["J"], center_size=c["center_size"], bbox=c["bbox"],
+          roi_cube_size=c["roi"], grid_spacing=c["spacing"], img_h=c["H"], img_w=c["W"], mean=S.MEAN, std=S.STD)
+dev = [t.cuda() for t in (inp["cam"], inp["intr"], inp["dist"])]
+one = inp["imgs"].cuda().unsqueeze(0).contiguous()
+p1 = NativePredictor(inp["sd_center"], inp["sd_hybrid"], time_batch=1, **kw)
+p1.set_calibration(*dev)
+ref = [t.clone() for t in p1.forward(one)]
+frames = one.expand(T, *one.shape[1:]).contiguous()
+streams = [torch.cuda.Stream() for _ in range(STREAMS)]
+preds = []
+for s in streams:
+    with torch.cuda.stream(s):
+        p = NativePredictor(inp["sd_center"], inp["sd_hybrid"], time_batch=T, **kw)
+        p.set_calibration(*dev)
+        preds.append(p)
+torch.cuda.synchronize()
+bad = 0
+for r in range(REPS):
+    outs = []
+    for s, p in zip(streams, preds):
+        with torch.cuda.stream(s):
+            outs.append([t.clone() for t in p.forward(frames)])
+    torch.cuda.synchronize()
+    for o in outs:
+        for t in range(T):
+            if not (torch.equal(o[0][t], ref[0][0]) and torch.equal(o[1][t], ref[1][0])):
+                bad += 1
+print("soak: %d runs x %d streams x %d frames, mismatching frames: %d" % (REPS, STREAMS, T, bad))
+sys.exit(1 if bad else 0)
