@@ -8,9 +8,10 @@ from jarvis_hybridnet_amd import synthetic as S
 from jarvis_hybridnet_amd._predictor import NativePredictor
 from tests import cases
 
-c = cases.PREDICTOR_CASES["cfg3"]
-inp = cases.predictor_inputs("cfg3")
-T, REPS, STREAMS = 32, int(os.environ.get("REPS", "20")), 3
+CASE = os.environ.get("CASE", "cfg3")
+c = cases.PREDICTOR_CASES[CASE]
+inp = cases.predictor_inputs(CASE)
+T, REPS, STREAMS = int(os.environ.get("T", "32")), int(os.environ.get("REPS", "20")), 3
 kw = dict(num_cameras=c["C"], num_joints=c["J"], center_size=c["center_size"], bbox=c["bbox"],
           roi_cube_size=c["roi"], grid_spacing=c["spacing"], img_h=c["H"], img_w=c["W"], mean=S.MEAN, std=S.STD)
 dev = [t.cuda() for t in (inp["cam"], inp["intr"], inp["dist"])]
