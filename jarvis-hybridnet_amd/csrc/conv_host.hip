@@ -69,6 +69,9 @@ int pack_conv_weights(const ConvDesc& d, const float* w, const float* b, bool tr
   std::vector<float> packed(phase_stride * d.nphase, 0.f);
   // kernels that read both operands 16 bytes at a time want two 8-channel steps per lane word
   const bool paired = d.nd == 2 && d.ostride > 1 && deconv4_eligible(cin_p, cout_p16);
+  // stride-2 3D convs: two taps per 16-byte weight word (conv_mfma.h, TAPPAIR)
+  const bool tap_paired = d.nd == 3 && d.k == 3 && d.stride == 2 && d.ostride == 1 && JH_ENV_KNOB("JH_CONV_TAPPAIR") != 0;
+  if (tap_paired) packed.assign((size_t)((ntap + 1) / 2) * nk8 * nb * 256, 0.f);
   // geometry of the source tensor
   int skd, sk;   // source kernel extents
   if (d.ostride > 1 && d.nd == 2) { skd = 1; sk = 4; }
@@ -95,14 +98,17 @@ int pack_conv_weights(const ConvDesc& d, const float* w, const float* b, bool tr
               const int kc8 = ci / 8, kq = (ci % 8) / 2, j = ci % 2;
               const int nbk = co / 16, nn = co % 16;
               const int lane = kq * 16 + nn;
-              if (paired)
+              if (tap_paired)
+                packed[((((size_t)(tap / 2)) * nk8 + kc8) * nb + nbk) * 256 + lane * 4 + (tap & 1) * 2 + j] = v;
+              else if (paired)
                 packed[ph * phase_stride + (((size_t)tap * (nk8 / 2) + kc8 / 2) * nb + nbk) * 256 + lane * 4 + (kc8 & 1) * 2 + j] = v;
               else
                 packed[ph * phase_stride + (((size_t)tap * nk8 + kc8) * nb + nbk) * 128 + lane * 2 + j] = v;
             }
         }
   }
-  out->cin_p = cin_p; out->cout_p16 = cout_p16; out->phase_stride = phase_stride; out->paired = paired ? 1 : 0;
+  out->cin_p = cin_p; out->cout_p16 = cout_p16; out->paired = tap_paired ? 2 : (paired ? 1 : 0);
+  out->phase_stride = tap_paired ? packed.size() : phase_stride;
   JH_CHECK_HIP(hipMalloc(&out->w, packed.size() * sizeof(float)));
   JH_CHECK_HIP(hipMemcpy(out->w, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
   out->bias = nullptr;
@@ -157,7 +163,8 @@ int launch_conv(const ConvDesc& d, const ConvWeights& w, const Act& x, const Act
     const int rc = launch_deconv4_fused(a, s);
     if (rc >= 0) return rc;
   }
-  JH_REQUIRE(!a.paired, "paired weight layout without a kernel that reads it");
+  JH_REQUIRE(!a.paired || (a.paired == 2 && d.nd == 3 && d.k == 3 && d.stride == 2),
+             "paired weight layout without a kernel that reads it");
   if (d.nd == 2) {
     const int small = (a.Wout <= 8) ? 1 : 0;
     // 16 x 16 tiles for high-resolution layers with few input channels

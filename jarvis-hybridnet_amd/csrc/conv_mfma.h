@@ -338,7 +338,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   // BREG: kernels whose whole weight set of a channel pass is small (1x1 convs, narrow 3x3
   // layers) fetch it into registers at the top of the pass, so the round trip to L2 runs under
   // the patch commit and the barriers instead of in front of every tap.
-  constexpr bool PIPE = (G::NT > 1) && (MR * NR * KC8 >= 12);
+  // (the stride-2 3D family always takes the plain loop: it has a tap-paired weight form there)
+  constexpr bool TAPPAIR = ND == 3 && K == 3 && STRIDE == 2;
+  constexpr bool PIPE = (G::NT > 1) && (MR * NR * KC8 >= 12) && !TAPPAIR;
   constexpr bool BREG = !PIPE && (G::NT == 1 ? KC8 * NR <= 16 : G::NT * KC8 * NR <= 9);   // (measured)
   for (int c0 = 0; c0 < a.cin_p; c0 += KC) {
     float2 breg[BREG ? G::NT : 1][KC8][NR];
@@ -536,6 +538,61 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
       for (int k8 = 0; k8 < KC8; ++k8)
         koff[k8] = min((c0 >> 3) + k8, nkc8_total - 1) * nb16_total * 64;
+      bool done = false;
+      if constexpr (TAPPAIR) {
+        if (a.paired == 2) {
+          // Tap-paired weights ([tap pair][channel step][column block][lane][4]: x, y = even tap, z, w =
+          // odd tap; the 28th tap is zero): one 16-byte load per (pair, step, column block) instead of
+          // two 8-byte ones.  This layer issues 3 weight loads + 1 LDS read per 6 MFMAs, and a memory
+          // instruction costs about one MFMA whatever its width (tools/mfma_valu_coissue.hip).
+          // Per accumulator the order of the products is the unpaired loop's: bit-identical.
+          done = true;
+          constexpr int NP = (G::NT + 1) / 2;
+          typedef unsigned int wu4 __attribute__((ext_vector_type(4)));
+          auto wload4 = [&](int idx4, int nr) __attribute__((always_inline)) -> float4 {
+            const wu4 v = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvo[nr] * 2, idx4 * 16, 0);
+            return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+          };
+          float4 b4[KC8][NR];
+#pragma unroll
+          for (int k8 = 0; k8 < KC8; ++k8)
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) b4[k8][nr] = wload4(koff[k8], nr);
+#pragma unroll
+          for (int p = 0; p < NP; ++p) {
+            constexpr int KHW = G::KH * G::KW;
+            const int t0 = 2 * p, t1 = min(2 * p + 1, G::NT - 1);       // (tap 27 re-reads tap 26: weights 0)
+            const int o0 = (((t0 / KHW) * G::PY + (t0 / G::KW) % G::KH) * G::PX + t0 % G::KW) * S2;
+            const int o1 = (((t1 / KHW) * G::PY + (t1 / G::KW) % G::KH) * G::PX + t1 % G::KW) * S2;
+            float2 a0[KC8][MR], a1[KC8][MR];
+            float4 bc[KC8][NR];
+#pragma unroll
+            for (int k8 = 0; k8 < KC8; ++k8)
+#pragma unroll
+              for (int mr = 0; mr < MR; ++mr) {
+                a0[k8][mr] = lds2[abase[mr] + o0 + k8 * 4];
+                a1[k8][mr] = lds2[abase[mr] + o1 + k8 * 4];
+              }
+            const int wn = min(p + 1, NP - 1) * tap_stride;
+#pragma unroll
+            for (int k8 = 0; k8 < KC8; ++k8)
+#pragma unroll
+              for (int nr = 0; nr < NR; ++nr) {
+                bc[k8][nr] = b4[k8][nr];
+                b4[k8][nr] = wload4(wn + koff[k8], nr);
+              }
+#define JH_TP_STEP(AV, AC, BC)                                                                              \
+  _Pragma("unroll") for (int mr = 0; mr < MR; ++mr) _Pragma("unroll") for (int nr = 0; nr < NR; ++nr)     \
+    acc[mr][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[k8][mr].AC, bc[k8][nr].BC, acc[mr][nr], 0, 0, 0);
+#pragma unroll
+            for (int k8 = 0; k8 < KC8; ++k8) { JH_TP_STEP(a0, x, x) JH_TP_STEP(a0, y, y) }
+#pragma unroll
+            for (int k8 = 0; k8 < KC8; ++k8) { JH_TP_STEP(a1, x, z) JH_TP_STEP(a1, y, w) }
+#undef JH_TP_STEP
+          }
+        }
+      }
+      if (!done) {
       float2 bn[KC8][NR];
 #pragma unroll
       for (int k8 = 0; k8 < KC8; ++k8)
@@ -575,6 +632,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
             }
           }
         }
+      }
     }
   }
 
