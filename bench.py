@@ -13,9 +13,12 @@ configs[1]'s geometry in fp32.
 
     python bench.py --gpus N --steps K --warmup W
 
-N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL); cameras are
-sharded over the ranks (jarvis_hybridnet_amd/distributed.py).  Rank 0 prints ONE
-JSON line.  `roofline` and `kernels` are measured live with HIP events around every
+N > 1 runs one rank per GPU over RCCL, cameras sharded over the ranks
+(jarvis_hybridnet_amd/distributed.py): either under torch.distributed.run (the driver's
+launch line; RANK / WORLD_SIZE come from the environment) or, when WORLD_SIZE is unset, this
+script starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` itself as a
+CHILD process -- before anything here touches the GPU -- and relays rank 0's line and the
+children's exit code.  Rank 0 prints ONE JSON line.  `roofline` and `kernels` are measured live with HIP events around every
 launch of profiled passes on one stream; `cpu_baseline` times the CPU oracle on the
 host cores (N = 1 only).
 """
@@ -119,6 +122,36 @@ def percentiles(ms):
     return dict(median=statistics.median(ms), p10=q(0.10), p90=q(0.90), n=len(ms))
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks as child processes (never an
+    exec: this parent stays a plain relay that has not touched the GPU), pass the children's
+    stderr through, print rank 0's JSON line last and return the children's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    json_line = None
+    for ln in reversed(lines):
+        if ln.lstrip().startswith("{"):
+            json_line = ln
+            break
+    for ln in lines:
+        if ln is not json_line:
+            print(ln, file=sys.stderr)
+    if json_line is not None and out.returncode == 0:
+        print(json_line, flush=True)
+    elif out.returncode == 0:
+        print("bench.py: the ranks exited 0 without printing a JSON line", file=sys.stderr)
+        return 1
+    return out.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,12 +187,19 @@ def main():
     ap.add_argument("--profile-passes", type=int, default=5)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))          # nothing above has touched the GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" %
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: run `python bench.py --gpus N` without a "
+                         "launcher, or torch.distributed.run with --nproc-per-node equal to --gpus" %
                          (args.gpus, world))
+    have = torch.cuda.device_count()                       # (does not initialise the GPU)
+    if have < world:
+        raise SystemExit("bench.py rank %d: --gpus %d needs %d GPUs on this node, %d visible" %
+                         (rank, world, world, have))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     sharded = world > 1 or args.force_sharded

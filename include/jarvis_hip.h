@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define JH_ABI_VERSION 2
+#define JH_ABI_VERSION 3
 
 const char* jh_last_error(void);
 int jh_abi_version(void);
@@ -153,6 +153,22 @@ int jh_predictor_stage_keypoints(jh_predictor* pr, const float* frames_dev,
  * subject: the reference returns (None, None), jarvis3D.py:187-190). */
 int jh_predictor_stage_3d(jh_predictor* pr, const float* heat_all_dev, int t0, float* points_dev,
                           float* conf_dev, int32_t* valid_dev, void* stream);
+/* Stage 2 fed directly from the all-gather of the per-rank detections (new design, no
+ * reference line): det_gathered is (n_blocks, T, C / n_blocks, 3), block b = the det output of
+ * the rank that owns cameras [b*C/n_blocks, (b+1)*C/n_blocks).  frames_u8 != 0: uint8 BGR
+ * frames as for the *_u8 entry points.  n_blocks = 1 is jh_predictor_stage_keypoints[_u8]. */
+int jh_predictor_stage_keypoints_gathered(jh_predictor* pr, const void* frames_dev, int frames_u8,
+                                          const float* det_gathered_dev, int n_blocks,
+                                          float* heat_dev, void* stream);
+/* Stage 3 reading the heatmaps IN PLACE from the receive buffer of the camera-sharded
+ * exchange (jarvis_hybridnet_amd/distributed.py; new design, no reference line): heat_blocks
+ * is (n_blocks, frames_per_block, C / n_blocks, B/2, B/2, Jp) -- block b holds cameras
+ * [b*C/n_blocks, (b+1)*C/n_blocks) as source rank b produced them -- and the T3 frames
+ * t_off .. t_off+T3-1 of every block are the frames t0 .. t0+T3-1 of the batch.
+ * n_blocks = 1, frames_per_block = T3, t_off = 0 is jh_predictor_stage_3d. */
+int jh_predictor_stage_3d_blocks(jh_predictor* pr, const float* heat_blocks_dev, int n_blocks,
+                                 int frames_per_block, int t_off, int t0, float* points_dev,
+                                 float* conf_dev, int32_t* valid_dev, void* stream);
 /* All three stages for cam_lo = 0, cam_n = num_cameras. */
 int jh_predictor_forward(jh_predictor* pr, const float* frames_dev, float* points_dev,
                          float* conf_dev, int32_t* valid_dev, void* stream);

@@ -28,7 +28,7 @@ class PredictorConfig(ctypes.Structure):
                 ("cam_n", ctypes.c_int32), ("mean", c_float * 3), ("std", c_float * 3)]
 
 
-ABI_VERSION = 2                      # JH_ABI_VERSION of include/jarvis_hip.h
+ABI_VERSION = 3                      # JH_ABI_VERSION of include/jarvis_hip.h
 # sizeof(jh_predictor_config): statically asserted on the C side (tests/abi_smoke.c) and here
 assert ctypes.sizeof(PredictorConfig) == 80
 
@@ -37,14 +37,15 @@ _WORKSPACES = {}
 
 def workspace(nbytes, device):
     """A cached device byte buffer of at least `nbytes` (the caller-provided workspace of the
-    stand-alone operators).  One buffer per device: those operators run on the current
-    stream, in order."""
-    key = str(device)
-    buf = _WORKSPACES.get(key)
-    if buf is None or buf.numel() < nbytes:
-        buf = _WORKSPACES[key] = torch.empty((max(int(nbytes), 256),), dtype=torch.uint8,
-                                             device=device)
-    return buf
+    stand-alone operators), one per (device, current stream): operators on different streams
+    never share scratch space.  A buffer that is outgrown is kept alive (not freed) because its
+    address may be baked into a captured hipGraph; graph-capturing callers that want to bound
+    that should own their workspace and call the C entry points directly."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    bufs = _WORKSPACES.setdefault(key, [])
+    if not bufs or bufs[-1].numel() < nbytes:
+        bufs.append(torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=device))
+    return bufs[-1]
 
 
 _SIGS = {
@@ -83,6 +84,10 @@ _SIGS = {
     "jh_predictor_stage_keypoints": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "jh_predictor_stage_3d": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                       c_void_p]),
+    "jh_predictor_stage_keypoints_gathered": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                                      c_void_p]),
+    "jh_predictor_stage_3d_blocks": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                             c_void_p, c_void_p, c_void_p]),
     "jh_profile_begin": (c_int, []),
     "jh_profile_end": (c_int, [ctypes.POINTER(c_int)]),
     "jh_profile_get": (c_int, [c_int, c_char_p, c_int, ctypes.POINTER(ctypes.c_double),

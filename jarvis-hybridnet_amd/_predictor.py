@@ -92,6 +92,20 @@ class NativePredictor:
         N.check(N.lib().jh_predictor_stage_3d(self.handle, N.ptr(heat_all), t0, N.ptr(points),
                                               N.ptr(conf), N.ptr(valid), N.stream()))
 
+    def stage_keypoints_gathered(self, frames, det_gathered, n_blocks, heat):
+        """Stage 2 reading the all-gathered detections (n_blocks, T, C/n_blocks, 3) in place."""
+        self._check_frames(frames, self.Cloc)
+        N.check(N.lib().jh_predictor_stage_keypoints_gathered(
+            self.handle, N.ptr(frames), int(frames.dtype == torch.uint8), N.ptr(det_gathered), n_blocks,
+            N.ptr(heat), N.stream()))
+
+    def stage_3d_blocks(self, heat_blocks, n_blocks, frames_per_block, t_off, t0, points, conf, valid):
+        """3D stage reading the exchange's receive buffer (n_blocks, frames_per_block, C/n_blocks,
+        h, w, Jp) in place: frames t_off .. t_off+T3-1 of every block."""
+        N.check(N.lib().jh_predictor_stage_3d_blocks(
+            self.handle, N.ptr(heat_blocks), n_blocks, frames_per_block, t_off, t0, N.ptr(points),
+            N.ptr(conf), N.ptr(valid), N.stream()))
+
     def debug(self, device):
         c3f = torch.empty((self.T, 3), device=device)
         c3i = torch.empty((self.T, 3), device=device, dtype=torch.int32)
@@ -145,6 +159,11 @@ class MultiStreamPredictor:
         key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in calib)
         if key == self._calib:
             return
+        # the key is only meaningful while the keyed tensors are alive: a freed calibration's
+        # address is handed out again by the caching allocator (same size, _version 0), and the
+        # next recording's tensors would then look like "the same tensors again".  Holding them
+        # makes address + version identify the contents.
+        self._calib_refs = tuple(calib)
         cur = torch.cuda.current_stream()
         for p, s in zip(self.preds, self.streams):
             s.wait_stream(cur)

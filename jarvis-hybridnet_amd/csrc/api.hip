@@ -93,6 +93,15 @@ __global__ void export_padded_kernel(const float* __restrict__ heat, float* __re
   }
 }
 
+// all-gathered detections (blocks, T, C/blocks, 3) -> (T, C, 3), camera = block * C/blocks + local
+__global__ void det_unblock_kernel(const float* __restrict__ src, float* __restrict__ dst, int T, int C,
+                                   int cpb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= T * C * 3) return;
+  const int k = i % 3, c = (i / 3) % C, t = i / (3 * C);
+  dst[i] = src[(((size_t)(c / cpb) * T + t) * cpb + c % cpb) * 3 + k];
+}
+
 __global__ void pack_det_kernel(const float* __restrict__ pts2d, const float* __restrict__ maxvals,
                                 float* __restrict__ det, int C) {
   const int c = threadIdx.x;
@@ -263,13 +272,13 @@ struct jh_predictor {
 
   // 3D stage for frames t0 .. t0+T3-1 of the batch (heat_all holds those frames)
   int run_3d(const float* heat_all, int t0, float* heatmap_final, float* points, float* conf,
-             hipStream_t s) {
+             hipStream_t s, const HeatLayout* layout = nullptr) {
     const double g3 = (double)G * G * G;
     // algorithmic traffic of the gather: every heatmap byte once in, the volume once out
     JH_PROF("reproject_gather", 0.0, 4.0 * T3 * ((double)C * Hh * Hh * J + g3 * J),
             launch_reproject(cam, intr, dist, c3i + t0 * 3, chm + t0 * C * 2, heat_all, coarse,
                              v2v->input.p, nullptr, T3, C, G, cfg.grid_spacing, hs, Jp,
-                             /*heat_pad=*/0, /*div255=*/1, s));
+                             /*heat_pad=*/0, /*div255=*/1, s, layout));
     if (v2v->run(s)) return 1;
     JH_PROF("softargmax", 0.0, 4.0 * T3 * (g3 / 8) * J,
             launch_softargmax(v2v->output.p, c3i + t0 * 3, sa_partial, sa_max, points, conf,
@@ -370,9 +379,18 @@ int jh_predictor_stage_center_u8(jh_predictor* pr, const uint8_t* frames_dev, fl
 }
 
 static int stage_keypoints_impl(jh_predictor* pr, const void* frames_dev, int src_u8,
-                                const float* det_all_dev, float* heat_dev, void* stream) {
+                                const float* det_all_dev, float* heat_dev, void* stream,
+                                int det_blocks = 1) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   const auto& c = pr->cfg;
+  if (det_blocks > 1) {
+    JH_REQUIRE(pr->C % det_blocks == 0, "cameras must divide evenly over the detection blocks");
+    const int n = pr->T * pr->C * 3;
+    hipLaunchKernelGGL(det_unblock_kernel, dim3((n + 255) / 256), dim3(256), 0, s, det_all_dev, pr->det_all,
+                       pr->T, pr->C, pr->C / det_blocks);
+    JH_CHECK_HIP(hipGetLastError());
+    det_all_dev = pr->det_all;
+  }
   // preds * (downsampling_scale * 2), jarvis3D.py:138-141,158-160
   const float sx2 = (float)((double)c.img_w / (double)c.center_size) * 2.f;
   const float sy2 = (float)((double)c.img_h / (double)c.center_size) * 2.f;
@@ -401,11 +419,38 @@ int jh_predictor_stage_keypoints_u8(jh_predictor* pr, const uint8_t* frames_dev,
   return stage_keypoints_impl(pr, frames_dev, 1, det_all_dev, heat_dev, stream);
 }
 
+int jh_predictor_stage_keypoints_gathered(jh_predictor* pr, const void* frames_dev, int frames_u8,
+                                          const float* det_gathered_dev, int n_blocks, float* heat_dev,
+                                          void* stream) {
+  JH_REQUIRE(n_blocks >= 1, "block count");
+  return stage_keypoints_impl(pr, frames_dev, frames_u8 != 0, det_gathered_dev, heat_dev, stream, n_blocks);
+}
+
 int jh_predictor_stage_3d(jh_predictor* pr, const float* heat_all_dev, int t0, float* points_dev,
                           float* conf_dev, int32_t* valid_dev, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   JH_REQUIRE(t0 >= 0 && t0 + pr->T3 <= pr->T, "frame range of the 3D stage");
   if (pr->run_3d(heat_all_dev, t0, nullptr, points_dev, conf_dev, s)) return 1;
+  if (valid_dev)
+    JH_CHECK_HIP(hipMemcpyAsync(valid_dev, pr->valid + t0, (size_t)pr->T3 * sizeof(int),
+                                hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
+int jh_predictor_stage_3d_blocks(jh_predictor* pr, const float* heat_blocks_dev, int n_blocks,
+                                 int frames_per_block, int t_off, int t0, float* points_dev,
+                                 float* conf_dev, int32_t* valid_dev, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  JH_REQUIRE(t0 >= 0 && t0 + pr->T3 <= pr->T, "frame range of the 3D stage");
+  JH_REQUIRE(n_blocks >= 1 && pr->C % n_blocks == 0, "cameras must divide evenly over the blocks");
+  JH_REQUIRE(t_off >= 0 && t_off + pr->T3 <= frames_per_block, "frame range inside a block");
+  HeatLayout lay;
+  const size_t plane = (size_t)pr->Hh * pr->Hh * pr->Jp;
+  lay.cams_per_block = pr->C / n_blocks;
+  lay.frame_stride = (size_t)lay.cams_per_block * plane;
+  lay.block_stride = (size_t)frames_per_block * lay.frame_stride;
+  if (pr->run_3d(heat_blocks_dev + (size_t)t_off * lay.frame_stride, t0, nullptr, points_dev, conf_dev, s,
+                 &lay)) return 1;
   if (valid_dev)
     JH_CHECK_HIP(hipMemcpyAsync(valid_dev, pr->valid + t0, (size_t)pr->T3 * sizeof(int),
                                 hipMemcpyDeviceToDevice, s));

@@ -53,6 +53,15 @@ struct Act {
   size_t bytes() const { return elems() * sizeof(float); }
 };
 
+// Where camera c of frame t of the 3D stage lives inside the heatmap buffer (floats):
+//   heat + (c / cams_per_block) * block_stride + t * frame_stride + (c % cams_per_block) * Hh*Hh*Jp
+// Dense (T, C, Hh, Hh, Jp) = one block.  The camera-sharded exchange delivers
+// (ranks, frames, cameras per rank, Hh, Hh, Jp): one block per source rank, read in place.
+struct HeatLayout {
+  int cams_per_block = 0;
+  size_t block_stride = 0, frame_stride = 0;
+};
+
 enum ActKind { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2 };
 
 // Optional per-launch timing with HIP events on the launch stream (bench.py's

@@ -17,7 +17,7 @@ namespace jh {
 int launch_reproject(const float* cam, const float* intr, const float* dist, const int* center3d,
                      const int* center_hm, const float* heat, float2* coarse, float* vol,
                      int* idx_out, int T, int C, int G, float spacing, int hs, int Jp,
-                     int heat_pad, int div255, hipStream_t s);
+                     int heat_pad, int div255, hipStream_t s, const HeatLayout* layout = nullptr);
 int launch_preprocess_resize(const void* frames, int src_u8, float* out, int N, int H, int W, int S,
                              const float* mean, const float* stdv, hipStream_t s);
 int launch_preprocess_crop(const void* frames, int src_u8, const int* center_hm, float* out, int T,

@@ -112,7 +112,7 @@ template <int Q>
 __global__ __launch_bounds__(256) void repro_gather_kernel(
     const float2* __restrict__ coarse, const float* __restrict__ heat, float* __restrict__ vol,
     int* __restrict__ idx_out, int C, int G, int hs, int Jp, int heat_pad, int div255, int ci_n,
-    int cj_n, FastDiv fgh, FastDiv frows, FastDiv fcjn, FastDiv fbpp) {
+    int cj_n, FastDiv fgh, FastDiv frows, FastDiv fcjn, FastDiv fbpp, HeatLayout lay) {
   extern __shared__ __attribute__((aligned(16))) float2 ctab[];   // [C][ci_n][cj_n][Gh]
   const BlockId bid = xcd_block();             // consecutive planes share heatmap regions
   const int t = bid.y;
@@ -166,12 +166,19 @@ __global__ __launch_bounds__(256) void repro_gather_kernel(
 #pragma unroll
   for (int q = 0; q < Q; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
   typedef float gf4 __attribute__((ext_vector_type(4)));
-  const size_t frame_floats = (size_t)C * Hh * Hh * Jp;     // (< 2^29: checked by the launcher)
-  const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(heat + (size_t)t * frame_floats), 0, (int)(frame_floats * 4), 0x00020000);
+  // one buffer resource per CAMERA plane (uniform: scalar registers): camera c of frame t lives at
+  // block c / cpb, frame t, local camera c % cpb of the (blocks, frames, cameras) heatmap layout
+  const int plane_bytes = Hh * Hh * Jp * 4;                 // (< 2^31: checked by the launcher)
+  const float* heat_t = heat + (size_t)t * lay.frame_stride;
   __syncthreads();
 
+  int cblk = 0, cloc = 0;                                   // c = cblk * cams_per_block + cloc
   for (int cb = 0; cb < C; cb += kCamBatch) {
+    static_assert(kCamBatch == 1, "one buffer resource per camera");
+    const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(heat_t + (size_t)cblk * lay.block_stride + (size_t)cloc * (plane_bytes >> 2)), 0,
+        plane_bytes, 0x00020000);
+    if (++cloc == lay.cams_per_block) { cloc = 0; ++cblk; }
     int src[kCamBatch];
 #pragma unroll
     for (int cc = 0; cc < kCamBatch; ++cc) {
@@ -194,11 +201,11 @@ __global__ __launch_bounds__(256) void repro_gather_kernel(
       if (idx_out && vox_ok && cb + cc < C) idx_out[((size_t)(t * C + c)) * nvox + vox] = iv * hs + iu;
       // padded -> stored heatmap coordinates (the zero border may be virtual)
       const int hx = iu - 1 + heat_pad, hy = iv - 1 + heat_pad;
-      // byte offset inside frame t's heatmaps; taps on the (virtual) zero border get bit 31: the
+      // byte offset inside the camera's heatmap; taps on the (virtual) zero border get bit 31: the
       // buffer load below is then out of range and returns 0 -- no branch, no 64-bit address
       src[cc] = (int)0x80000000;
       if (cb + cc < C && hx >= 0 && hy >= 0 && hx < Hh && hy < Hh)
-        src[cc] = (((c * Hh + hy) * Hh + hx) * Jp) * 4;
+        src[cc] = ((hy * Hh + hx) * Jp) * 4;
     }
     float4 h[Q][kCamBatch];
 #pragma unroll
@@ -251,10 +258,17 @@ __global__ __launch_bounds__(256) void repro_gather_kernel(
 int launch_reproject(const float* cam, const float* intr, const float* dist, const int* center3d,
                      const int* center_hm, const float* heat, float2* coarse, float* vol,
                      int* idx_out, int T, int C, int G, float spacing, int hs, int Jp,
-                     int heat_pad, int div255, hipStream_t s) {
+                     int heat_pad, int div255, hipStream_t s, const HeatLayout* layout) {
   const int Gh = G / 2;
+  const int Hst = hs - 2 + 2 * heat_pad;
+  HeatLayout lay;                        // default: dense (T, C, Hh, Hh, Jp)
+  lay.cams_per_block = C;
+  lay.frame_stride = (size_t)C * Hst * Hst * Jp;
+  lay.block_stride = 0;
+  if (layout) lay = *layout;
+  JH_REQUIRE(lay.cams_per_block >= 1 && C % lay.cams_per_block == 0, "cameras per heatmap block");
   JH_REQUIRE(G % 2 == 0 && Jp % 8 == 0 && Jp <= 64, "reprojection shape");
-  JH_REQUIRE((size_t)C * hs * hs * Jp * 4 < ((size_t)1 << 31), "heatmaps of one frame exceed 2 GB");
+  JH_REQUIRE((size_t)hs * hs * Jp * 4 < ((size_t)1 << 31), "one camera's heatmap exceeds 2 GB");
   ReproCalib cal{cam, intr, dist};
   const int nvc = Gh * Gh * Gh;
   hipLaunchKernelGGL(repro_coarse_kernel, dim3((nvc + 255) / 256, C, T), dim3(256), 0, s, cal,
@@ -272,7 +286,7 @@ int launch_reproject(const float* cam, const float* intr, const float* dist, con
   case QV:                                                                                     \
     hipLaunchKernelGGL(repro_gather_kernel<QV>, grid, dim3(256), lds, s, coarse, heat, vol,    \
                        idx_out, C, G, hs, Jp, heat_pad, div255, ci_n, cj_n, make_fastdiv(Gh),   \
-                       make_fastdiv(ci_n * cj_n), make_fastdiv(cj_n), make_fastdiv(bpp));      \
+                       make_fastdiv(ci_n * cj_n), make_fastdiv(cj_n), make_fastdiv(bpp), lay); \
     break;
   switch (Jp / 4) {
     JH_RG(2) JH_RG(4) JH_RG(6) JH_RG(8) JH_RG(10) JH_RG(12) JH_RG(14) JH_RG(16)

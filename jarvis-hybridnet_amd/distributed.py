@@ -33,8 +33,14 @@ the 3D stage by frame; bench.py reports both.
 `comm` is the object the collectives are called on (default: torch.distributed).  Tests
 inject an in-process communicator to run several emulated ranks on one GPU.
 
-`stages` is any object with the four methods used below, which is what lets the
-world_size-2 gloo test on CPU drive this file with the oracle as compute.
+`stages` is any object with the three methods used below (stage_center,
+stage_keypoints_gathered, stage_3d_blocks), which is what lets the world_size-2 gloo test on
+CPU drive this file with the oracle as compute.
+
+No torch compute op runs between the stages: the detections and the heatmaps are consumed
+in the layout the collectives deliver them in -- (ranks, frames, cameras per rank, ...) --
+by the *_gathered / *_blocks entry points of the library, and points + confidences leave the
+3D stage inside one flat buffer that is all-gathered as it is.
 """
 import torch
 import torch.distributed as dist
@@ -89,11 +95,16 @@ class ShardedPredictor:
             self.heat_recv = torch.empty((world * self.T3, self.Cloc) + tuple(heat_shape), **f32)
         else:
             self.heat_recv = torch.empty((world * self.T, self.Cloc) + tuple(heat_shape), **f32)
-        self.res_local = torch.zeros((self.T3, self.J, 4), **f32)
+        # results: [points (T3,J,3) | conf (T3,J)] in ONE flat buffer per rank, written in place by
+        # the 3D stage and gathered as it is
+        self.n_pts = self.T3 * self.J * 3
+        self.res_local = torch.zeros((self.T3 * self.J * 4,), **f32)
+        self.pts_local = self.res_local[:self.n_pts].view(self.T3, self.J, 3)
+        self.conf_local = self.res_local[self.n_pts:].view(self.T3, self.J)
         self.valid_local = torch.zeros((self.T3,), device=device, dtype=torch.int32)
-        n_res = self.T3 if three_d == "rank0" else world * self.T3
-        self.res_all = torch.empty((n_res, self.J, 4), **f32)
-        self.valid_all = torch.empty((n_res,), device=device, dtype=torch.int32)
+        n_res = 1 if three_d == "rank0" else world
+        self.res_all = torch.empty((n_res * self.T3 * self.J * 4,), **f32)
+        self.valid_all = torch.empty((n_res * self.T3,), device=device, dtype=torch.int32)
         self._pending = None                     # exchange of the time batch in flight
 
     def step(self, frames_local):
@@ -108,13 +119,12 @@ class ShardedPredictor:
     #     -> exchange(i+1) started asynchronously
     def submit(self, frames_local):
         """Start time batch i+1; returns the results of batch i (None on the first call)."""
-        W, Cl = self.world, self.Cloc
+        W = self.world
         self.st.stage_center(frames_local, self.det_local)
         self.comm.all_gather_into_tensor(self.det_gather, self.det_local, group=self.group)
-        det_all = (self.det_gather.view(W, self.T, Cl, 3).permute(1, 0, 2, 3)
-                   .reshape(self.T, self.C, 3).contiguous())
         prev = self._finish()
-        self.st.stage_keypoints(frames_local, det_all, self.heat_local)
+        # det_gather is (W, T, Cl, 3): read in place, camera = source rank * Cl + local camera
+        self.st.stage_keypoints_gathered(frames_local, self.det_gather, W, self.heat_local)
         if self.exchange == "alltoall":
             # block r of the send buffer = my cameras' heatmaps of rank r's frames
             self._pending = self.comm.all_to_all_single(self.heat_recv, self.heat_local,
@@ -131,37 +141,38 @@ class ShardedPredictor:
     def _finish(self):
         if self._pending is None:
             return None
-        W, T3, Cl = self.world, self.T3, self.Cloc
+        W = self.world
         self._pending.wait()
         self._pending = None
-        if self.exchange == "alltoall":
-            mine = self.heat_recv.view((W, T3, Cl) + self.heat_recv.shape[2:])
-        else:
-            mine = self.heat_recv.view((W, self.T, Cl) + self.heat_recv.shape[2:])[
-                :, self.t_lo:self.t_lo + T3]
         if self.three_d == "rank0":
             if self.rank == 0:
-                self._run_3d(mine)
+                self._run_3d()
             # results of the whole time batch from rank 0 to everybody
             self.comm.broadcast(self.res_local, self._global_rank0(), group=self.group)
             self.comm.broadcast(self.valid_local, self._global_rank0(), group=self.group)
-            res = self.res_local.clone()
-            return res[..., :3], res[..., 3], self.valid_local.clone()
-        self._run_3d(mine)
+            return self._split(self.res_local.view(1, -1), self.valid_local)
+        self._run_3d()
         self.comm.all_gather_into_tensor(self.res_all, self.res_local, group=self.group)
         self.comm.all_gather_into_tensor(self.valid_all, self.valid_local, group=self.group)
-        res = self.res_all.reshape(self.T, self.J, 4).clone()      # the buffers are reused
-        return res[..., :3], res[..., 3], self.valid_all.reshape(self.T).clone()
+        return self._split(self.res_all.view(W, -1), self.valid_all)
 
-    def _run_3d(self, mine):
-        # (world, T3, Cloc, ...) -> (T3, C, ...): camera c = source_rank * Cloc + local camera
-        T3 = self.T3
-        heat_all = mine.permute(1, 0, 2, 3, 4, 5).reshape((T3, self.C) + mine.shape[3:]).contiguous()
-        pts = torch.empty((T3, self.J, 3), device=heat_all.device)
-        conf = torch.empty((T3, self.J), device=heat_all.device)
-        self.st.stage_3d(heat_all, self.t_lo, pts, conf, self.valid_local)
-        self.res_local[..., :3] = pts
-        self.res_local[..., 3] = conf
+    def _split(self, res, valid):
+        """(ranks, [points | conf]) -> points (T,J,3), conf (T,J), valid (T): fresh tensors (the
+        result buffers are reused by the next time batch)."""
+        n = res.shape[0] * self.T3
+        cf = torch.contiguous_format
+        return (res[:, :self.n_pts].clone(memory_format=cf).view(n, self.J, 3),
+                res[:, self.n_pts:].clone(memory_format=cf).view(n, self.J), valid.clone())
+
+    def _run_3d(self):
+        # heat_recv is (W, frames per block, Cloc, h, w, Jp): camera c = source rank * Cloc + local
+        # camera.  Read in place; with the all-gather only frames [t_lo, t_lo + T3) of every block.
+        if self.exchange == "alltoall":
+            fpb, t_off = self.T3, 0
+        else:
+            fpb, t_off = self.T, self.t_lo
+        self.st.stage_3d_blocks(self.heat_recv, self.world, fpb, t_off, self.t_lo, self.pts_local,
+                                self.conf_local, self.valid_local)
 
     def _global_rank0(self):
         """broadcast() takes the GLOBAL rank of the source: rank 0 of this group."""

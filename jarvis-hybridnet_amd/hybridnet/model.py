@@ -32,10 +32,14 @@ class HybridNetBackbone(NativeModule):
         self.v2vNet = V2VNet(cfg.KEYPOINTDETECT.NUM_JOINTS, cfg.KEYPOINTDETECT.NUM_JOINTS)
 
     def _predictor(self, batch, bbox):
-        key = (batch, bbox, weights_fingerprint(self))     # reloads of effTrack / v2vNet count
+        fp = weights_fingerprint(self)                      # reloads of effTrack / v2vNet count
+        key = (batch, bbox, fp)
         pr = self._plans.get(key)
         if pr is None:
-            self._invalidate()                              # stale plans of older weights
+            # drop the plans of OLDER weights only; plans of other (batch, bbox) shapes built from
+            # the current weights stay (alternating batch sizes must not rebuild every call)
+            for k in [k for k in self._plans if k[2] != fp]:
+                self._plans.pop(k).close()
             c = self.cfg
             pr = NativePredictor(
                 None, flat_state(self), num_cameras=c.HYBRIDNET.NUM_CAMERAS,

@@ -7,9 +7,32 @@ Video decoding (cv2.VideoCapture) and project management are outside the hot pat
 """
 import csv
 import itertools
+import json
 import os
+import re
 
 import torch
+
+_PLAIN = re.compile(r"^[A-Za-z0-9_./\\][A-Za-z0-9_./\\ +=,@%-]*$")
+_RESERVED = {"", "~", "null", "true", "false", "yes", "no", "on", "off", "y", "n"}
+
+
+def yaml_scalar(val):
+    """One YAML scalar.  Numbers and None as such; strings plain when that is unambiguous,
+    double-quoted (JSON escapes are valid YAML) otherwise -- a `recording_path` containing
+    ': ', '#', quotes or a leading '-' / '*' must still load as the same string."""
+    if val is None:
+        return "null"
+    if isinstance(val, bool):
+        return "true" if val else "false"
+    if isinstance(val, (int, float)):
+        return repr(val)
+    s = str(val)
+    numberlike = re.match(r"^[-+.]?[0-9]", s) is not None or s.lower() in (".inf", ".nan")
+    if (_PLAIN.match(s) and s.lower() not in _RESERVED and not numberlike and s == s.strip()
+            and ": " not in s and " #" not in s and not s.endswith(":")):
+        return s
+    return json.dumps(s)
 
 
 def create_header(writer, cfg):
@@ -20,12 +43,12 @@ def create_header(writer, cfg):
     writer.writerow(coords)
 
 
-def create_info_file(params):
-    """info.yaml with the four keys the reference writes (plain YAML mapping)."""
+def create_info_file(params, keys=("recording_path", "dataset_name", "frame_start", "number_frames")):
+    """info.yaml with the four keys the reference writes (predict3D.py:149-155; a block
+    mapping in the reference's key order; strings quoted where YAML needs it)."""
     with open(os.path.join(params.output_dir, "info.yaml"), "w") as f:
-        for key in ("recording_path", "dataset_name", "frame_start", "number_frames"):
-            val = getattr(params, key)
-            f.write("%s: %s\n" % (key, "null" if val is None else val))
+        for key in keys:
+            f.write("%s: %s\n" % (key, yaml_scalar(getattr(params, key))))
 
 
 def frame_row(points3D, confidences, num_joints):

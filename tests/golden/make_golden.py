@@ -162,6 +162,26 @@ def case_reprojection():
     save("reprojection", out)
 
 
+def case_reprojection_hash():
+    """64-bit hash of every camera plane of the reference's gather-index field
+    (ReprojectionLayer.reprojectPoints) for all reprojection cases, incl. the 14 M indices of
+    cfg5 that are too many to commit in full (tests/util.py::index_plane_hashes)."""
+    from tests.util import index_plane_hashes
+    out = {}
+    for tag, (C, J, G, spacing, bbox, W, H, focal, seed) in cases.REPRO_CASES.items():
+        cfg = R.make_cfg(num_cameras=C, num_joints=J, roi=G * spacing, spacing=spacing, bbox=bbox)
+        inp = cases.repro_inputs(tag)
+        layer = ReprojectionLayer(cfg)
+        with torch.no_grad():
+            grid = layer.grid + inp["center3d"][0]
+            ref_idx = layer.reprojectPoints(grid, inp["cam"][0], inp["intr"][0], inp["dist"][0],
+                                            inp["center_hm"][0])
+        out[tag] = dict(n=int(ref_idx.numel()), planes=index_plane_hashes(ref_idx))
+        print(tag, tuple(ref_idx.shape), out[tag]["planes"][:2])
+    with open(os.path.join(HERE, "reprojection_index_hashes.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 def case_v2v():
     out = {}
     for tag, (J, G, wseed, xseed) in cases.V2V_CASES.items():
@@ -457,6 +477,40 @@ def case_csv():
     print("wrote data3D_expected.csv (%d bytes)" % len(buf.getvalue()))
 
 
+def case_csv2d():
+    """data2D.csv wire format (prediction/predict2D.py:71-109,120-125): header by the
+    reference's own create_header, rows by its row loop over the reference predictor's outputs
+    of the predictor2d fixture, one 'NaN' row."""
+    import csv
+    import io
+    from jarvis.prediction.predict2D import create_header
+    g = dict(np.load(os.path.join(HERE, "predictor2d.npz")))
+    J = 12
+    cfg = R.ns(KEYPOINT_NAMES=["joint%d" % i for i in range(J)],
+               KEYPOINTDETECT=R.ns(NUM_JOINTS=J))
+    buf = io.StringIO()
+    writer = csv.writer(buf, delimiter=",", quotechar='"', quoting=csv.QUOTE_MINIMAL)
+    create_header(writer, cfg)
+    for tag in ("cam0_j12", "cam2_j12", None):
+        if tag is not None:
+            # predict2D.py:98-103
+            points2D = torch.from_numpy(g[tag + ".points2D"]).cpu().numpy()
+            confidences = torch.from_numpy(g[tag + ".confidences"]).cpu().numpy()
+            row = []
+            for i, point in enumerate(points2D):
+                row = row + point.tolist() + [confidences[i]]
+            writer.writerow(row)
+        else:
+            # predict2D.py:105-109
+            row = []
+            for i in range(cfg.KEYPOINTDETECT.NUM_JOINTS * 3):
+                row = row + ["NaN"]
+            writer.writerow(row)
+    with open(os.path.join(HERE, "data2D_expected.csv"), "w", newline="") as f:
+        f.write(buf.getvalue())
+    print("wrote data2D_expected.csv (%d bytes)" % len(buf.getvalue()))
+
+
 def case_analysis():
     """analysis/analyze.py:22-96 run for real with its collaborators (project manager,
     Dataset3D, predictor, calibration loader) replaced by seeded stand-ins: the three CSV
@@ -515,7 +569,7 @@ def case_analysis():
     shutil.rmtree(out_root)
 
 
-ALL = dict(analysis=case_analysis, calibration=case_calibration, csv=case_csv, predictor2d=case_predictor2d, state_spec=case_state_spec, efficienttrack=case_efficienttrack,
+ALL = dict(analysis=case_analysis, reprojection_hash=case_reprojection_hash, csv2d=case_csv2d, calibration=case_calibration, csv=case_csv, predictor2d=case_predictor2d, state_spec=case_state_spec, efficienttrack=case_efficienttrack,
            reprojection=case_reprojection, v2v=case_v2v, geometry=case_geometry,
            hybridnet=case_hybridnet, predictor=case_predictor)
 

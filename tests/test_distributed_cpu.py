@@ -74,6 +74,19 @@ class OracleStages:
                 heat[t].zero_()
                 heat[t, :, :, :, :J] = hm.permute(0, 2, 3, 1)       # channel-last, Jp padded
 
+    # the layouts the collectives deliver (what the library's *_gathered / *_blocks entry points
+    # read in place): re-ordered here with torch, then the plain stage
+    def stage_keypoints_gathered(self, frames, det_gathered, n_blocks, heat):
+        Tn = frames.shape[0]
+        det_all = det_gathered.view(n_blocks, Tn, -1, 3).permute(1, 0, 2, 3).reshape(Tn, C, 3)
+        self.stage_keypoints(frames, det_all, heat)
+
+    def stage_3d_blocks(self, heat_blocks, n_blocks, frames_per_block, t_off, t0, pts, conf, valid):
+        hb = heat_blocks.view((n_blocks, frames_per_block) + tuple(heat_blocks.shape[1:]))
+        T3 = pts.shape[0]
+        mine = hb[:, t_off:t_off + T3].permute(1, 0, 2, 3, 4, 5)
+        self.stage_3d(mine.reshape((T3, C) + tuple(hb.shape[3:])), t0, pts, conf, valid)
+
     def stage_3d(self, heat_all, t0, pts, conf, valid):
         cam, intr, dist_ = self.calib
         with torch.no_grad():

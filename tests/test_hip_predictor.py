@@ -617,3 +617,73 @@ def test_multi_stream_predictor_equals_single_stream():
         torch.cuda.synchronize()
         for x, y in zip(g, ref):
             assert torch.equal(x, y)
+
+
+def test_multi_stream_set_calibration_sees_new_values():
+    """A second recording's calibration -- fresh tensors of the same shapes, possibly at the very
+    addresses of the first recording's freed ones (the caching allocator hands them out again,
+    `_version` 0) -- must reach every stream's predictor.  Checked against a single
+    NativePredictor given the same calibration."""
+    import gc
+    from jarvis_hybridnet_amd import synthetic as S
+    from jarvis_hybridnet_amd._predictor import MultiStreamPredictor, NativePredictor
+    c = cases.PREDICTOR_CASES["cfg2"]
+    inp = cases.predictor_inputs("cfg2")
+    kw = dict(num_cameras=c["C"], num_joints=c["J"], center_size=c["center_size"], bbox=c["bbox"],
+              roi_cube_size=c["roi"], grid_spacing=c["spacing"], img_h=c["H"], img_w=c["W"],
+              mean=S.MEAN, std=S.STD, time_batch=1)
+    msp = MultiStreamPredictor(lambda: NativePredictor(inp["sd_center"], inp["sd_hybrid"], **kw), streams=2)
+    single = NativePredictor(inp["sd_center"], inp["sd_hybrid"], **kw)
+    frames = cuda(inp["imgs"]).unsqueeze(0).contiguous()
+    other = S.ring_calibration(c["C"], c["W"], c["H"], 905.0)       # a slightly different rig
+    results = []
+    for calib in ((inp["cam"], inp["intr"], inp["dist"]), other):
+        dev = [t.clone().cuda() for t in calib]                     # fresh tensors per "recording"
+        msp.set_calibration(*dev)
+        got = [[t.clone() for t in msp.forward(frames)] for _ in range(2)]
+        msp.synchronize()
+        single.set_calibration(*dev)
+        ref = [t.clone() for t in single.forward(frames)]
+        torch.cuda.synchronize()
+        for g in got:
+            for x, y in zip(g, ref):
+                assert torch.equal(x, y)
+        results.append(ref[0])
+        del dev, got
+        gc.collect()                                                # the first recording's tensors die here
+    assert max_err(results[0], results[1]) > 1e-2                   # the two rigs really differ
+
+
+def test_predict2d_frames_end_to_end(tmp_path, golden):
+    """SURVEY 8f rank 2, second half on the GPU: frames in (fp32 RGB and uint8 BGR as decoded),
+    data2D.csv out; rows of the fp32 fixture frames are the reference's own rows."""
+    import csv
+    from jarvis_hybridnet_amd.prediction.jarvis2D import JarvisPredictor2D
+    from jarvis_hybridnet_amd.prediction.predict2D import predict2D_frames
+    tags = ["cam0_j12", "cam2_j12"]
+    c = cases.PREDICTOR2D_CASES[tags[0]]
+    ins = [cases.predictor2d_inputs(t) for t in tags]
+    cfg = make_cfg(dict(J=c["J"], bbox=c["bbox"], C=1, roi=32, spacing=2), c["center_size"])
+    cfg.KEYPOINT_NAMES = ["joint%d" % i for i in range(c["J"])]
+    pred = JarvisPredictor2D(cfg, ins[0]["sd_center"], ins[0]["sd_kp"])
+    frames = [i["img"][0] for i in ins]
+    expected = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                                 "data2D_expected.csv"), newline="").read().splitlines()
+    for tb in (1, 2, 3):
+        out = tmp_path / ("f32_tb%d" % tb)
+        n = predict2D_frames(pred, frames, cfg, str(out), time_batch=tb)
+        rows = open(out / "data2D.csv", newline="").read().splitlines()
+        assert n == 2 and len(rows) == 4 and rows[:2] == expected[:2]
+        for got, want in zip(rows[2:], expected[2:4]):
+            g, w = got.split(","), want.split(",")
+            assert g[0::3] == w[0::3] and g[1::3] == w[1::3]         # integer pixels: exact text
+            assert max(abs(float(a) - float(b)) for a, b in zip(g[2::3], w[2::3])) < 1e-5
+    # uint8 BGR as cv2 delivers it, a dark frame in the middle; single calls == time batch 2
+    u8 = [(f.permute(1, 2, 0)[..., [2, 1, 0]] * 255).round().to(torch.uint8).numpy() for f in frames]
+    dark = u8[0] * 0
+    n1 = predict2D_frames(pred, [u8[0], dark, u8[1]], cfg, str(tmp_path / "u8_1"))
+    n2 = predict2D_frames(pred, [u8[0], dark, u8[1]], cfg, str(tmp_path / "u8_2"), time_batch=2)
+    r1 = list(csv.reader(open(tmp_path / "u8_1" / "data2D.csv")))
+    r2 = list(csv.reader(open(tmp_path / "u8_2" / "data2D.csv")))
+    assert n1 == n2 == 3 and r1 == r2 and len(r1) == 5
+    assert r1[2] != r1[4] and all(len(r) == 3 * c["J"] for r in r1)

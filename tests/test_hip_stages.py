@@ -2,7 +2,7 @@
 API) against the CPU oracle on the seeded cases of tests/cases.py.
 
 Floating-point bars (fp32 kernels, different summation order than the CPU
-libraries): network outputs <= 1e-3 x max magnitude, 3D coordinates <= 1e-3 mm
+libraries): network outputs <= 1e-4 x max magnitude, 3D coordinates <= 1e-3 mm
 (north-star tolerance).  Integer paths (gather indices, argmax, truncated
 centres) must be bit-exact.
 """
@@ -32,7 +32,9 @@ def test_efficienttrack(tag):
     torch.cuda.synchronize()
     e, e1 = rel_err(res2, ref), rel_err(res1, ref1)
     report("efficienttrack", tag=tag, rel=e, rel_res1=e1, absmax=float(ref.abs().max()))
-    assert e < 1e-3 and e1 < 1e-3
+    # fp32 kernels with another summation order than the CPU library: measured <= 1.3e-5; a wrong tap
+    # in a low-energy layer moves the output by far more than 1e-4
+    assert e < 1e-4 and e1 < 1e-4
     assert tuple(res1.shape) == tuple(ref1.shape)
     net.compute_res1 = False                   # inference form: the dead branch is skipped
     none1, again = net(cuda(x))
@@ -107,6 +109,15 @@ def test_reprojection(tag, golden):
     full = golden_indices(g, tag)
     mism_golden = int((idx.cpu() != full).sum()) if full is not None else -1
     assert mism_golden <= 0, "gather indices must equal the reference's, bit for bit"
+    # every index of every camera plane, also where the full field is not committed (cfg5: 14 M)
+    import json
+    import os
+    from tests.util import index_plane_hashes
+    hashes = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                                         "reprojection_index_hashes.json")))[tag]
+    assert hashes["n"] == idx.numel()
+    assert index_plane_hashes(idx[0] if idx.dim() == 5 else idx) == hashes["planes"], \
+        "a gather index differs from the reference's"
     if tag == "cfg5":       # oracle too slow/large for the test budget: fixtures only
         report("reprojection", tag=tag, idx_mismatch_vs_reference=mism_golden)
         return

@@ -104,3 +104,96 @@ def test_analyze_frames_writes_the_reference_csvs(tmp_path, monkeypatch):
     import pytest
     with pytest.raises(NotImplementedError, match="project management"):
         analyze_validation_data("some_project")
+
+
+def test_csv2d_wire_format(golden, tmp_path):
+    """SURVEY 8f rank 2, second half: data2D.csv (predict2D.py:71-109,120-125) byte-equal to the
+    file the reference's own create_header + row loop wrote for the predictor2d fixture
+    (make_golden.case_csv2d); info.yaml of the 2D driver has three keys; per-video file names."""
+    from jarvis_hybridnet_amd.prediction import predict2D as P
+    g = golden("predictor2d")
+    J = 12
+    cfg = NS(KEYPOINT_NAMES=["joint%d" % i for i in range(J)], KEYPOINTDETECT=NS(NUM_JOINTS=J))
+    buf = io.StringIO()
+    writer = csv.writer(buf, delimiter=",", quotechar='"', quoting=csv.QUOTE_MINIMAL)
+    P.create_header(writer, cfg)
+    for tag in ("cam0_j12", "cam2_j12"):
+        writer.writerow(P.frame_row(torch.from_numpy(g[tag + ".points2D"]),
+                                    torch.from_numpy(g[tag + ".confidences"]), J))
+    writer.writerow(P.frame_row(None, None, J))
+    expected = open(os.path.join(HERE, "golden", "data2D_expected.csv"), newline="").read()
+    assert buf.getvalue() == expected
+    params = NS(output_dir=str(tmp_path), recording_path="/rec/cam0.mp4", frame_start=0, number_frames=-1)
+    P.create_info_file(params)
+    assert open(tmp_path / "info.yaml").read().splitlines() == [
+        "recording_path: /rec/cam0.mp4", "frame_start: 0", "number_frames: -1"]
+    assert P.csv_filename("/rec/cam0.mp4", False) == "data2D.csv"
+    assert P.csv_filename(os.path.join("/rec", "Camera_B.take1.avi"), True) == "Camera_B_data2D.csv"
+
+
+def test_predict2D_frames_driver(golden, tmp_path):
+    """The 2D driver loop with a stub predictor (host logic: grouping into time batches, padding
+    of the last group, NaN rows, one CSV per recording)."""
+    from jarvis_hybridnet_amd.prediction import predict2D as P
+    g = golden("predictor2d")
+    J = 12
+    cfg = NS(KEYPOINT_NAMES=["joint%d" % i for i in range(J)], KEYPOINTDETECT=NS(NUM_JOINTS=J))
+    ptsA, cfA = torch.from_numpy(g["cam0_j12.points2D"]), torch.from_numpy(g["cam0_j12.confidences"])
+    ptsB, cfB = torch.from_numpy(g["cam2_j12.points2D"]), torch.from_numpy(g["cam2_j12.confidences"])
+
+    class Stub:
+        """frame value 0 -> case A, 1 -> case B, 2 -> no detection"""
+        def _one(self, x):
+            k = int(x.flatten()[0])
+            return [(ptsA, cfA), (ptsB, cfB), (None, None)][k]
+
+        def __call__(self, img):
+            return self._one(img[0])
+
+        def forward_batch(self, x):
+            res = [self._one(f) for f in x]
+            pts = torch.stack([r[0] if r[0] is not None else torch.zeros_like(ptsA) for r in res])
+            conf = torch.stack([r[1] if r[1] is not None else torch.zeros_like(cfA) for r in res])
+            return pts.int(), conf, torch.tensor([int(r[0] is not None) for r in res], dtype=torch.int32)
+
+    import unittest.mock as um
+    frames = [torch.full((3, 4, 4), float(k)) for k in (0, 1, 2)]
+    expected = open(os.path.join(HERE, "golden", "data2D_expected.csv"), newline="").read()
+    with um.patch.object(torch.Tensor, "cuda", lambda self, *a, **k: self):
+        for tb in (1, 2):
+            out = tmp_path / ("tb%d" % tb)
+            n = P.predict2D_frames(Stub(), frames, cfg, str(out), time_batch=tb)
+            assert n == 3 and open(out / "data2D.csv", newline="").read() == expected
+        u8 = [torch.full((4, 4, 3), k, dtype=torch.uint8) for k in (0, 1, 2)]
+        out = tmp_path / "u8"
+        assert P.predict2D_frames(Stub(), u8, cfg, str(out)) == 3
+        assert open(out / "data2D.csv", newline="").read() == expected
+        params = NS(recording_path="/rec", frame_start=0, number_frames=3)
+        done = P.predict2D_recordings(Stub(), {"/rec/a.mp4": frames, "/rec/b.x.mp4": frames[:1]}, cfg,
+                                      str(tmp_path / "multi"), params)
+    assert done == {"a_data2D.csv": 3, "b_data2D.csv": 1}
+    assert open(tmp_path / "multi" / "a_data2D.csv", newline="").read() == expected
+    assert os.path.isfile(tmp_path / "multi" / "info.yaml")
+
+
+def test_info_yaml_scalars_round_trip(tmp_path):
+    """info.yaml stays valid YAML for any recording path (': ', '#', quotes, leading '-', strings
+    that look like numbers / booleans / null): a YAML loader returns what was written."""
+    import yaml
+    from jarvis_hybridnet_amd.prediction.predict3D import create_info_file
+    nasty = ["/data/rec: take #2", "a 'quoted' \"name\"", "- dash", "*star", "123", "1e3", "true", "null", "~",
+             "", " lead", "trail ", "C:\\rec\\cam 1", "/plain/path_1.mp4", "tab\there", "uml\u00e4ut", "a:"]
+    for i, path in enumerate(nasty):
+        out = tmp_path / str(i)
+        os.makedirs(out)
+        create_info_file(NS(output_dir=str(out), recording_path=path, dataset_name=None if i % 2 else path,
+                            frame_start=i, number_frames=-1))
+        got = yaml.safe_load(open(out / "info.yaml"))
+        assert got == {"recording_path": path, "dataset_name": None if i % 2 else path, "frame_start": i,
+                       "number_frames": -1}, (path, got)
+        assert list(got) == ["recording_path", "dataset_name", "frame_start", "number_frames"]
+    # the common case keeps the plain form the reference's dumper writes
+    create_info_file(NS(output_dir=str(tmp_path), recording_path="/rec/a", dataset_name="Example_Dataset",
+                        frame_start=5, number_frames=10))
+    assert open(tmp_path / "info.yaml").read() == (
+        "recording_path: /rec/a\ndataset_name: Example_Dataset\nframe_start: 5\nnumber_frames: 10\n")

@@ -136,3 +136,22 @@ def test_predictor2d(golden, tag):
         return
     check_summary(g, tag + ".points2D", pts)
     check_summary(g, tag + ".confidences", conf, **TOL)
+
+
+def test_index_plane_hashes_pin_the_committed_fields(golden):
+    """tests/golden/reprojection_index_hashes.json (per camera plane, all cases incl. the 14 M
+    indices of cfg5) agrees with the full index fields that ARE committed."""
+    import json
+    import os
+    from tests.util import golden_indices, index_plane_hashes
+    here = os.path.dirname(os.path.abspath(__file__))
+    hashes = json.load(open(os.path.join(here, "golden", "reprojection_index_hashes.json")))
+    g = golden("reprojection")
+    for tag in ("tiny", "cfg2", "cfg3"):
+        full = golden_indices(g, tag)
+        assert full is not None and full.numel() == hashes[tag]["n"]
+        assert index_plane_hashes(full) == hashes[tag]["planes"]
+        bad = full.clone()
+        bad.view(-1)[12345 % full.numel()] += 1
+        assert index_plane_hashes(bad) != hashes[tag]["planes"]
+    assert hashes["cfg5"]["n"] == 16 * 96 ** 3 and len(hashes["cfg5"]["planes"]) == 16

@@ -40,6 +40,17 @@ def golden_indices(g, tag):
     return torch.from_numpy(np.cumsum(g[key].astype(np.int64), axis=-1))
 
 
+def index_plane_hashes(idx):
+    """Position-sensitive 64-bit hash of every camera's (G,G,G) gather-index plane:
+    sum_i idx[i] * (i * 0x9E3779B97F4A7C15 + 1) mod 2^64.  A single wrong index anywhere changes
+    its camera's hash; used where the full field is too large to commit (cfg5: 14 M indices)."""
+    a = np.ascontiguousarray(idx.detach().cpu().numpy()).astype(np.uint64)
+    a = a.reshape(a.shape[0], -1)
+    with np.errstate(over="ignore"):
+        w = np.arange(a.shape[1], dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(1)
+        return [int((row * w).sum(dtype=np.uint64)) for row in a]
+
+
 def same_cpu_as_golden():
     """True when this machine's CPU model is the one the fixtures were made on
     (torch's CPU kernels, hence the oracle's last bits, depend on the ISA)."""
