@@ -53,7 +53,7 @@ CONFIGS = {
 }
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_HBM_GBS = 8000.0
-PMC_TRAFFIC = os.path.join("profiles", "r02_pmc_traffic.json")
+PMC_TRAFFIC = os.path.join("profiles", "r03_pmc_traffic.json")
 
 
 def usable_cores():
@@ -233,7 +233,10 @@ def main():
     size = args.model_size
     sd_c = S.efficienttrack_weights(size, 1, 50)
     sd_h = S.hybridnet_weights(size, c["J"], 51)
-    distinct = [S.blob_frames(calib, c["W"], c["H"], c["J"], 52 + i)[0] for i in range(min(T, 2))]
+    # T_distinct seeded frame sets (different subject positions, hence different detections, crop
+    # windows and voxel-grid centres in every slot of a time batch); frame 0 is the fixture case
+    n_distinct = min(T, int(os.environ.get("JH_BENCH_DISTINCT", str(args.time_batch))))
+    distinct = [S.blob_frames(calib, c["W"], c["H"], c["J"], 52 + i)[0] for i in range(n_distinct)]
 
     def device_frames(cam_lo, cam_n, frames=T):
         """(frames, cam_n, 3, H, W) on the GPU, assembled there from the distinct frames so
@@ -415,17 +418,29 @@ def main():
                                           "multiplies" if "wino" in top["kernel"] else ""))
         roof["algorithmic_bytes"] = top["algorithmic_bytes_per_launch"]
         # HBM bytes of that kernel: rocprofv3 cannot run inside this process, so the PMC passes
-        # (tools/pmc_traffic.sh: the same bench command under --pmc FETCH_SIZE / WRITE_SIZE) are
-        # committed under profiles/ and scaled to this run's time batch
+        # (tools/pmc_traffic.sh: this bench command under --pmc FETCH_SIZE / WRITE_SIZE) are
+        # committed under profiles/ together with the SHA-256 of the csrc/ tree they were taken
+        # on.  They are reported -- scaled to this run's time batch -- only when this run's
+        # sources are that tree; otherwise `traffic` stays null and says why.
         try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from pmc_traffic import csrc_sha256
             pmc = json.load(open(os.path.join(ROOT, PMC_TRAFFIC)))
-            if top["kernel"] in pmc:
+            if pmc.get("csrc_sha256") != csrc_sha256():
+                roof["traffic_note"] = "%s was measured on another csrc/ tree (sha256 %s...)" % (
+                    PMC_TRAFFIC, str(pmc.get("csrc_sha256"))[:12])
+            elif top["kernel"] in pmc:
                 e = pmc[top["kernel"]]
-                roof["traffic"] = e["hbm_bytes_per_launch"] * T_prof / e["time_batch"]
-                roof["traffic_source"] = "%s (rocprofv3 --pmc passes of `%s`, time batch %d)" % (
-                    PMC_TRAFFIC, e.get("command", "bench.py"), e["time_batch"])
-        except (OSError, ValueError, KeyError):
-            pass
+                roof["traffic"] = e["hbm_bytes_per_launch"] * T_prof / pmc["time_batch"]
+                roof["traffic_source"] = "%s (rocprofv3 --pmc passes of `%s`, csrc sha256 %s...)" % (
+                    PMC_TRAFFIC, pmc.get("command", "bench.py"), pmc["csrc_sha256"][:12])
+                for row in table:                     # same figure for the other measured kernels
+                    if row["kernel"] in pmc and isinstance(pmc[row["kernel"]], dict):
+                        row["traffic"] = pmc[row["kernel"]]["hbm_bytes_per_launch"] * T_prof / pmc["time_batch"]
+            else:
+                roof["traffic_note"] = "no PMC entry for %s in %s" % (top["kernel"], PMC_TRAFFIC)
+        except (OSError, ValueError, KeyError, ImportError) as e:
+            roof["traffic_note"] = "no usable %s: %r" % (PMC_TRAFFIC, e)
         line["roofline"] = roof
         line["kernels"] = [{k: (round(v, 5) if isinstance(v, float) else v) for k, v in row.items()
                             if k not in ("algorithmic_flops_per_launch", "algorithmic_bytes_per_launch")}
@@ -529,14 +544,21 @@ def main():
             f1 = fr[:1].contiguous()
             o1 = (torch.empty((1, c["J"], 3), device=dev), torch.empty((1, c["J"]), device=dev),
                   torch.empty((1,), device=dev, dtype=torch.int32))
-            for _ in range(10):
-                p1.forward(f1, o1)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(100):
-                p1.forward(f1, o1)
-            torch.cuda.synchronize()
-            line["single_frame_latency_ms"] = 1e3 * (time.perf_counter() - t0) / 100
+            lat = {}
+            for mode, on in (("graph", True), ("eager", False)):
+                p1.graph_replay = on
+                for _ in range(10):
+                    p1.forward(f1, o1)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(100):
+                    p1.forward(f1, o1)
+                torch.cuda.synchronize()
+                lat[mode] = 1e3 * (time.perf_counter() - t0) / 100
+            # the product path (JarvisPredictor3D.forward, one frame set per call as the reference
+            # driver calls it) replays a hipGraph; `eager` = the same ~150 launches one by one
+            line["single_frame_latency_ms"] = lat["graph"]
+            line["single_frame_latency_ms_eager"] = lat["eager"]
             del p1
         except Exception as e:
             line["single_frame_latency_ms"] = repr(e)[:200]

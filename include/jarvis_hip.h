@@ -172,6 +172,17 @@ int jh_predictor_stage_3d_blocks(jh_predictor* pr, const float* heat_blocks_dev,
 /* All three stages for cam_lo = 0, cam_n = num_cameras. */
 int jh_predictor_forward(jh_predictor* pr, const float* frames_dev, float* points_dev,
                          float* conf_dev, int32_t* valid_dev, void* stream);
+/* jh_predictor_forward[_u8] as ONE hipGraph launch.  The reference driver calls the predictor
+ * with one frame set at a time (jarvis/prediction/predict3D.py:82-85); at that size the ~150
+ * launches of a forward are launch-bound, so a predictor with time_batch == 1 captures its
+ * forward on first use and replays the graph afterwards (the call's frame pointer goes through a
+ * device cell, results are copied out of the predictor's buffers: any pointers may be passed on
+ * every call, results are bit-identical to the plain launches).  Default: on for time_batch
+ * == 1, off otherwise (environment JH_GRAPH=0 / 1 overrides for the process); this switches it
+ * per predictor.  Not used while jh_profile_begin() is active or while the caller's stream is
+ * itself being captured. */
+int jh_predictor_set_graph_replay(jh_predictor* pr, int on);
+int jh_predictor_graph_replay(const jh_predictor* pr);
 /* uint8 ingest (jarvis/prediction/predict3D.py:72-80): the
  * same three entry points for frames (T,cam_n,H,W,3) uint8 BGR exactly as the video
  * decoder delivers them.  The `.float().permute(0,3,1,2)[:, [2,1,0]] / 255.` of the

@@ -77,6 +77,8 @@ _SIGS = {
     "jh_predictor_create": (c_int, [c_void_p, c_void_p, ctypes.POINTER(PredictorConfig),
                                     ctypes.POINTER(c_void_p)]),
     "jh_predictor_destroy": (None, [c_void_p]),
+    "jh_predictor_set_graph_replay": (c_int, [c_void_p, c_int]),
+    "jh_predictor_graph_replay": (c_int, [c_void_p]),
     "jh_predictor_launches": (c_int64, [c_void_p]),
     "jh_predictor_device_bytes": (c_int64, [c_void_p]),
     "jh_predictor_set_calibration": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

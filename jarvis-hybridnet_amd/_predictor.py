@@ -39,6 +39,15 @@ class NativePredictor:
 
     __del__ = close
 
+    # ---- graph replay of the whole forward (default: on for time_batch == 1) ---
+    @property
+    def graph_replay(self):
+        return bool(N.lib().jh_predictor_graph_replay(self.handle))
+
+    @graph_replay.setter
+    def graph_replay(self, on):
+        N.check(N.lib().jh_predictor_set_graph_replay(self.handle, int(bool(on))))
+
     # ---- calibration -----------------------------------------------------
     def set_calibration(self, cam, intr, dist):
         N.check(N.lib().jh_predictor_set_calibration(

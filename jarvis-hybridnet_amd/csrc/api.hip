@@ -102,6 +102,19 @@ __global__ void det_unblock_kernel(const float* __restrict__ src, float* __restr
   dst[i] = src[(((size_t)(c / cpb) * T + t) * cpb + c % cpb) * 3 + k];
 }
 
+// graph replays: this call's frame pointer into the device cell the captured kernels read it from
+__global__ void set_cell_kernel(const void** cell, const void* value) { *cell = value; }
+// ... and the results out of the predictor's own buffers into this call's output tensors
+__global__ void copy_out_kernel(const float* __restrict__ gp, const float* __restrict__ gc,
+                                const int* __restrict__ gv, float* __restrict__ points,
+                                float* __restrict__ conf, int* __restrict__ valid, int n_pts, int n_conf,
+                                int n_valid) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_pts) points[i] = gp[i];
+  if (i < n_conf) conf[i] = gc[i];
+  if (valid && i < n_valid) valid[i] = gv[i];
+}
+
 __global__ void pack_det_kernel(const float* __restrict__ pts2d, const float* __restrict__ maxvals,
                                 float* __restrict__ det, int C) {
   const int c = threadIdx.x;
@@ -269,6 +282,18 @@ struct jh_predictor {
   float2* coarse = nullptr;
   double* sa_partial = nullptr;
   int* sa_max = nullptr;
+  // hipGraph replay of the whole forward (the reference driver's call pattern: one frame set per
+  // call, predict3D.py:82-85 -- 150+ launches of small kernels, launch-bound when issued one by one)
+  int use_graph = 0;
+  const void** frames_cell = nullptr;        // device: the frame pointer of the current call
+  const void* const* cur_cell = nullptr;     // non-null only while the forward is being captured
+  float *g_points = nullptr, *g_conf = nullptr;
+  hipStream_t gstream = nullptr;             // capture stream (the caller's may be the null stream)
+  hipGraphExec_t gexec[2] = {nullptr, nullptr};   // [fp32 frames, uint8 frames]
+  ~jh_predictor() {
+    for (auto& e : gexec) if (e) (void)hipGraphExecDestroy(e);
+    if (gstream) (void)hipStreamDestroy(gstream);
+  }
 
   // 3D stage for frames t0 .. t0+T3-1 of the batch (heat_all holds those frames)
   int run_3d(const float* heat_all, int t0, float* heatmap_final, float* points, float* conf,
@@ -329,12 +354,32 @@ int jh_predictor_create(const jh_params* center_params, const jh_params* hybrid_
   if (m.get(reinterpret_cast<void**>(&pr->sa_partial), (size_t)T * pr->Jp * 4 * kLimbs * sizeof(double))) return 1;
   if (m.get(reinterpret_cast<void**>(&pr->sa_max), (size_t)T * pr->Jp * sizeof(int))) return 1;
   JH_CHECK_HIP(hipMemset(pr->valid, 0, (size_t)T * sizeof(int)));
+  // graph replay: by default for the single-frame-set call (T = 1), where the forward is
+  // launch-bound; JH_GRAPH=1 / 0 forces it on / off for every time batch
+  const int knob = JH_ENV_KNOB("JH_GRAPH");
+  pr->use_graph = knob >= 0 ? (knob != 0) : (pr->T == 1);
+  if (pr->Cloc == pr->C && pr->T3 == pr->T && pr->center) {
+    if (m.get(reinterpret_cast<void**>(&pr->frames_cell), 256)) return 1;
+    if (m.get(reinterpret_cast<void**>(&pr->g_points), (size_t)T * pr->J * 3 * sizeof(float))) return 1;
+    if (m.get(reinterpret_cast<void**>(&pr->g_conf), (size_t)T * pr->J * sizeof(float))) return 1;
+    JH_CHECK_HIP(hipStreamCreateWithFlags(&pr->gstream, hipStreamNonBlocking));
+  } else {
+    pr->use_graph = 0;
+  }
   JH_CHECK_HIP(hipDeviceSynchronize());
   *out = pr.release();
   return 0;
 }
 
 void jh_predictor_destroy(jh_predictor* pr) { delete pr; }
+
+int jh_predictor_set_graph_replay(jh_predictor* pr, int on) {
+  JH_REQUIRE(pr, "bad argument");
+  JH_REQUIRE(!on || pr->gstream, "graph replay needs a predictor that owns all cameras and CenterDetect");
+  pr->use_graph = on != 0;
+  return 0;
+}
+int jh_predictor_graph_replay(const jh_predictor* pr) { return pr ? pr->use_graph : 0; }
 
 int64_t jh_predictor_launches(const jh_predictor* pr) {
   return (int64_t)((pr->center ? pr->center->launches() : 0) + pr->kp->launches() +
@@ -361,7 +406,7 @@ static int stage_center_impl(jh_predictor* pr, const void* frames_dev, int src_u
   const int N = pr->T * pr->Cloc, S = pr->cfg.center_size;
   JH_PROF("preprocess_resize", 0.0, (double)N * S * S * (12.0 * (src_u8 ? 1 : 4) + 3 * 4),
           launch_preprocess_resize(frames_dev, src_u8, pr->center->input.p, N, pr->cfg.img_h,
-                                   pr->cfg.img_w, S, pr->cfg.mean, pr->cfg.std, s));
+                                   pr->cfg.img_w, S, pr->cfg.mean, pr->cfg.std, s, pr->cur_cell));
   if (pr->center->run(s)) return 1;
   const Act& h = pr->center->heat;
   JH_PROF("center_argmax", 0.0, 4.0 * N * h.H * h.W,
@@ -402,7 +447,7 @@ static int stage_keypoints_impl(jh_predictor* pr, const void* frames_dev, int sr
                                 hipMemcpyDeviceToDevice, s));
   JH_PROF("preprocess_crop", 0.0, (double)pr->T * pr->Cloc * pr->B * pr->B * (src_u8 ? 15.0 : 24.0),
           launch_preprocess_crop(frames_dev, src_u8, pr->chm, pr->kp->input.p, pr->T, pr->Cloc, pr->C,
-                                 c.cam_lo, c.img_h, c.img_w, pr->B, c.mean, c.std, s));
+                                 c.cam_lo, c.img_h, c.img_w, pr->B, c.mean, c.std, s, pr->cur_cell));
   if (pr->kp->run(s)) return 1;
   if (heat_dev && heat_dev != pr->kp->heat.p)
     JH_CHECK_HIP(hipMemcpyAsync(heat_dev, pr->kp->heat.p, pr->kp->heat.bytes(),
@@ -457,13 +502,58 @@ int jh_predictor_stage_3d_blocks(jh_predictor* pr, const float* heat_blocks_dev,
   return 0;
 }
 
+static int forward_eager(jh_predictor* pr, const void* frames_dev, int src_u8, float* points_dev,
+                         float* conf_dev, int32_t* valid_dev, void* stream) {
+  if (stage_center_impl(pr, frames_dev, src_u8, pr->det_all, stream)) return 1;
+  if (stage_keypoints_impl(pr, frames_dev, src_u8, pr->det_all, nullptr, stream)) return 1;
+  return jh_predictor_stage_3d(pr, pr->kp->heat.p, 0, points_dev, conf_dev, valid_dev, stream);
+}
+
+// The forward as ONE graph launch.  Captured on first use (on the predictor's own stream: the
+// caller's may be the null stream, which cannot capture) with the frame pointer read through
+// `frames_cell` and the results written to the predictor's own buffers, so the same executable
+// graph serves every later call: set the cell, launch the graph, copy the results out -- three
+// submissions instead of ~150.  Calibration lives in the predictor's buffers (set_calibration
+// copies into them), weights are immutable for the life of a predictor: nothing to invalidate.
+static int forward_graph(jh_predictor* pr, const void* frames_dev, int src_u8, float* points_dev,
+                         float* conf_dev, int32_t* valid_dev, hipStream_t s) {
+  hipGraphExec_t& exec = pr->gexec[src_u8 ? 1 : 0];
+  if (!exec) {
+    hipGraph_t g = nullptr;
+    JH_CHECK_HIP(hipStreamBeginCapture(pr->gstream, hipStreamCaptureModeRelaxed));
+    pr->cur_cell = pr->frames_cell;
+    const int rc = forward_eager(pr, nullptr, src_u8, pr->g_points, pr->g_conf, nullptr, pr->gstream);
+    pr->cur_cell = nullptr;
+    const hipError_t e = hipStreamEndCapture(pr->gstream, &g);
+    if (rc) { if (g) (void)hipGraphDestroy(g); return 1; }
+    JH_CHECK_HIP(e);
+    const hipError_t ei = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (ei != hipSuccess) exec = nullptr;
+    JH_CHECK_HIP(ei);
+  }
+  hipLaunchKernelGGL(set_cell_kernel, dim3(1), dim3(1), 0, s, pr->frames_cell, frames_dev);
+  JH_CHECK_HIP(hipGetLastError());
+  JH_CHECK_HIP(hipGraphLaunch(exec, s));
+  const int n_pts = pr->T * pr->J * 3;
+  hipLaunchKernelGGL(copy_out_kernel, dim3((n_pts + 255) / 256), dim3(256), 0, s, pr->g_points, pr->g_conf,
+                     pr->valid, points_dev, conf_dev, valid_dev, n_pts, pr->T * pr->J, pr->T);
+  JH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 static int forward_impl(jh_predictor* pr, const void* frames_dev, int src_u8, float* points_dev,
                         float* conf_dev, int32_t* valid_dev, void* stream) {
   JH_REQUIRE(pr->Cloc == pr->C && pr->cfg.cam_lo == 0, "forward needs all cameras local");
   JH_REQUIRE(pr->T3 == pr->T, "forward needs time_batch_3d == time_batch");
-  if (stage_center_impl(pr, frames_dev, src_u8, pr->det_all, stream)) return 1;
-  if (stage_keypoints_impl(pr, frames_dev, src_u8, pr->det_all, nullptr, stream)) return 1;
-  return jh_predictor_stage_3d(pr, pr->kp->heat.p, 0, points_dev, conf_dev, valid_dev, stream);
+  JH_REQUIRE(frames_dev && points_dev && conf_dev, "null frame / output pointer");
+  // per-launch profiling needs the launches one by one; a caller that is itself capturing this
+  // stream gets the plain launches too (its graph then holds them)
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (pr->use_graph && !profiler().on) (void)hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cs);
+  if (!pr->use_graph || profiler().on || cs != hipStreamCaptureStatusNone)
+    return forward_eager(pr, frames_dev, src_u8, points_dev, conf_dev, valid_dev, stream);
+  return forward_graph(pr, frames_dev, src_u8, points_dev, conf_dev, valid_dev, static_cast<hipStream_t>(stream));
 }
 int jh_predictor_forward(jh_predictor* pr, const float* frames_dev, float* points_dev,
                          float* conf_dev, int32_t* valid_dev, void* stream) {

@@ -449,4 +449,25 @@ int launch_from_channel_last(const Act& src, float* dst, hipStream_t s) {
   return 0;
 }
 
+__global__ __launch_bounds__(256) void zero_kernel(uint4* __restrict__ p16, size_t n16, unsigned* __restrict__ tail,
+                                                   int ntail) {
+  const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (size_t i = i0; i < n16; i += (size_t)gridDim.x * blockDim.x) p16[i] = make_uint4(0, 0, 0, 0);
+  if (i0 < (size_t)ntail) tail[i0] = 0u;
+}
+
+int launch_zero(void* p, size_t bytes, hipStream_t s) {
+  JH_REQUIRE(bytes % 4 == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0, "zeroed range: 16-byte aligned, whole words");
+  if (bytes == 0) return 0;
+  const size_t n16 = bytes / 16;
+  const int ntail = (int)((bytes - n16 * 16) / 4);
+  size_t blocks = (n16 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<uint4*>(p), n16,
+                     reinterpret_cast<unsigned*>(static_cast<char*>(p) + n16 * 16), ntail);
+  JH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 }  // namespace jh

@@ -35,7 +35,10 @@ __device__ __forceinline__ float frame_px(const void* frames, size_t n, int c, i
 template <int SRC>
 __global__ __launch_bounds__(256) void preprocess_resize_kernel(
     const void* __restrict__ frames, float* __restrict__ out, int N, int H, int W, int S,
-    float sy, float sx, float3 mean, float3 stdv) {
+    float sy, float sx, float3 mean, float3 stdv, const void* const* __restrict__ frames_cell) {
+  // graph replays: the frame pointer of THIS call is read from a device cell (a captured launch
+  // would otherwise keep the pointer of the call it was captured on)
+  if (frames_cell) frames = *frames_cell;
   const size_t total = (size_t)N * S * S;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (size_t)gridDim.x * blockDim.x) {
@@ -62,17 +65,18 @@ __global__ __launch_bounds__(256) void preprocess_resize_kernel(
 }
 
 int launch_preprocess_resize(const void* frames, int src_u8, float* out, int N, int H, int W, int S,
-                             const float* mean, const float* stdv, hipStream_t s) {
+                             const float* mean, const float* stdv, hipStream_t s,
+                             const void* const* frames_cell) {
   const size_t total = (size_t)N * S * S;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 8192) blocks = 8192;
   const float3 m = make_float3(mean[0], mean[1], mean[2]), sd = make_float3(stdv[0], stdv[1], stdv[2]);
   if (src_u8)
     hipLaunchKernelGGL(preprocess_resize_kernel<1>, dim3(blocks), dim3(256), 0, s, frames, out, N, H,
-                       W, S, (float)H / (float)S, (float)W / (float)S, m, sd);
+                       W, S, (float)H / (float)S, (float)W / (float)S, m, sd, frames_cell);
   else
     hipLaunchKernelGGL(preprocess_resize_kernel<0>, dim3(blocks), dim3(256), 0, s, frames, out, N, H,
-                       W, S, (float)H / (float)S, (float)W / (float)S, m, sd);
+                       W, S, (float)H / (float)S, (float)W / (float)S, m, sd, frames_cell);
   JH_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -81,7 +85,9 @@ int launch_preprocess_resize(const void* frames, int src_u8, float* out, int N, 
 template <int SRC>
 __global__ __launch_bounds__(256) void preprocess_crop_kernel(
     const void* __restrict__ frames, const int* __restrict__ center_hm, float* __restrict__ out,
-    int T, int Cloc, int C, int cam0, int H, int W, int B, float3 mean, float3 stdv) {
+    int T, int Cloc, int C, int cam0, int H, int W, int B, float3 mean, float3 stdv,
+    const void* const* __restrict__ frames_cell) {
+  if (frames_cell) frames = *frames_cell;
   const size_t total = (size_t)T * Cloc * B * B;
   const int hw = B / 2;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -105,17 +111,17 @@ __global__ __launch_bounds__(256) void preprocess_crop_kernel(
 
 int launch_preprocess_crop(const void* frames, int src_u8, const int* center_hm, float* out, int T,
                            int Cloc, int C, int cam0, int H, int W, int B, const float* mean,
-                           const float* stdv, hipStream_t s) {
+                           const float* stdv, hipStream_t s, const void* const* frames_cell) {
   const size_t total = (size_t)T * Cloc * B * B;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 8192) blocks = 8192;
   const float3 m = make_float3(mean[0], mean[1], mean[2]), sd = make_float3(stdv[0], stdv[1], stdv[2]);
   if (src_u8)
     hipLaunchKernelGGL(preprocess_crop_kernel<1>, dim3(blocks), dim3(256), 0, s, frames, center_hm,
-                       out, T, Cloc, C, cam0, H, W, B, m, sd);
+                       out, T, Cloc, C, cam0, H, W, B, m, sd, frames_cell);
   else
     hipLaunchKernelGGL(preprocess_crop_kernel<0>, dim3(blocks), dim3(256), 0, s, frames, center_hm,
-                       out, T, Cloc, C, cam0, H, W, B, m, sd);
+                       out, T, Cloc, C, cam0, H, W, B, m, sd, frames_cell);
   JH_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -504,8 +510,8 @@ int launch_softargmax(const float* x, const int* center3d, double* partial, int*
   const int q = Jp / 4;
   JH_REQUIRE(q >= 1 && q <= 64 && J <= 256, "soft-argmax joint count");
   const int rows = 256 / q;
-  JH_CHECK_HIP(hipMemsetAsync(partial, 0, (size_t)T * Jp * 4 * kLimbs * sizeof(double), s));
-  JH_CHECK_HIP(hipMemsetAsync(pmax, 0, (size_t)T * Jp * sizeof(int), s));
+  if (launch_zero(partial, (size_t)T * Jp * 4 * kLimbs * sizeof(double), s)) return 1;
+  if (launch_zero(pmax, (size_t)T * Jp * sizeof(int), s)) return 1;
   const int ppb = rows * 8;
   dim3 grid((P + ppb - 1) / ppb, T);
   hipLaunchKernelGGL(softargmax_partial_kernel, grid, dim3(256), (size_t)rows * q * 20 * sizeof(float),

@@ -292,6 +292,13 @@ int launch_stem_conv(const Act& x, const float* w_dev, const Act& y, double* sta
 int launch_deconv_c1(const Act& x, const double* stats, float inv_cnt, int in_act, const float* w,
                      const Act& y, hipStream_t s);
 
+// Zero `bytes` (a multiple of 4) of device memory with a KERNEL.  The forward path uses this
+// instead of hipMemsetAsync: inside a captured hipGraph a small memset node was observed not to
+// take effect before the kernels that follow it (stale soft-argmax maxima of an earlier call
+// survived a replay, tests/test_hip_predictor.py::test_multi_stream_set_calibration_sees_new_values),
+// while kernel nodes of a linear chain are ordered reliably.
+int launch_zero(void* p, size_t bytes, hipStream_t s);
+
 // ---------------------------------------------------------------- layout moves
 // NCHW/NCDHW fp32 -> channel-last padded (pad channels zeroed) and back.
 int launch_to_channel_last(const float* src, const Act& dst, hipStream_t s);

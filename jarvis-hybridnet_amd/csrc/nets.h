@@ -19,10 +19,11 @@ int launch_reproject(const float* cam, const float* intr, const float* dist, con
                      int* idx_out, int T, int C, int G, float spacing, int hs, int Jp,
                      int heat_pad, int div255, hipStream_t s, const HeatLayout* layout = nullptr);
 int launch_preprocess_resize(const void* frames, int src_u8, float* out, int N, int H, int W, int S,
-                             const float* mean, const float* stdv, hipStream_t s);
+                             const float* mean, const float* stdv, hipStream_t s,
+                             const void* const* frames_cell = nullptr);
 int launch_preprocess_crop(const void* frames, int src_u8, const int* center_hm, float* out, int T,
                            int Cloc, int C, int cam0, int H, int W, int B, const float* mean,
-                           const float* stdv, hipStream_t s);
+                           const float* stdv, hipStream_t s, const void* const* frames_cell = nullptr);
 int launch_center_argmax(const float* heat, float* det, int N, int Hh, int Wh, int Cp,
                          hipStream_t s);
 int launch_center2d(const float* det, int* center_hm, int* valid, int T, float sx, float sy, int hw,

@@ -68,7 +68,7 @@ int Plan::finish() {
 }
 
 int Plan::run(hipStream_t s) {
-  JH_CHECK_HIP(hipMemsetAsync(arena_, 0, arena_doubles_ * sizeof(double), s));
+  if (launch_zero(arena_, arena_doubles_ * sizeof(double), s)) return 1;
   Profiler& pf = profiler();
   for (auto& op : ops_) {
     if (pf.on) pf.begin(op.name, op.flops, op.bytes, s);

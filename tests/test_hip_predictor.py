@@ -640,8 +640,8 @@ def test_multi_stream_set_calibration_sees_new_values():
     for calib in ((inp["cam"], inp["intr"], inp["dist"]), other):
         dev = [t.clone().cuda() for t in calib]                     # fresh tensors per "recording"
         msp.set_calibration(*dev)
-        got = [[t.clone() for t in msp.forward(frames)] for _ in range(2)]
-        msp.synchronize()
+        got = [msp.forward(frames) for _ in range(2)]               # one batch per stream
+        msp.synchronize()                                           # (outputs are ready only now)
         single.set_calibration(*dev)
         ref = [t.clone() for t in single.forward(frames)]
         torch.cuda.synchronize()
@@ -687,3 +687,68 @@ def test_predict2d_frames_end_to_end(tmp_path, golden):
     r2 = list(csv.reader(open(tmp_path / "u8_2" / "data2D.csv")))
     assert n1 == n2 == 3 and r1 == r2 and len(r1) == 5
     assert r1[2] != r1[4] and all(len(r) == 3 * c["J"] for r in r1)
+
+
+def test_single_frame_forward_replays_a_graph():
+    """The reference driver's call pattern (one frame set per call, predict3D.py:82-85): a T = 1
+    predictor captures its forward into a hipGraph on first use and replays it.  Different frame
+    tensors (new pointers), fp32 and uint8 frames, a side stream, new calibration values: every
+    call must give the bits of the plain launches."""
+    from jarvis_hybridnet_amd import synthetic as S
+    from jarvis_hybridnet_amd._predictor import NativePredictor
+    c = cases.PREDICTOR_CASES["cfg2"]
+    inp = cases.predictor_inputs("cfg2")
+    calib = (inp["cam"], inp["intr"], inp["dist"])
+    kw = dict(num_cameras=c["C"], num_joints=c["J"], center_size=c["center_size"], bbox=c["bbox"],
+              roi_cube_size=c["roi"], grid_spacing=c["spacing"], img_h=c["H"], img_w=c["W"],
+              mean=S.MEAN, std=S.STD, time_batch=1)
+    dev = [cuda(t) for t in calib]
+    # leave stale, non-zero scratch contents behind (a destroyed predictor's device memory is what
+    # the next hipMalloc hands out): a replay that skipped any of its zero-initialisations shows
+    z = NativePredictor(inp["sd_center"], S.hybridnet_weights("small", c["J"], 99), **kw)
+    z.set_calibration(*dev)
+    z.forward(cuda(inp["imgs"]).unsqueeze(0))
+    torch.cuda.synchronize()
+    z.close()
+    g = NativePredictor(inp["sd_center"], inp["sd_hybrid"], **kw)
+    e = NativePredictor(inp["sd_center"], inp["sd_hybrid"], **kw)
+    assert g.graph_replay and e.graph_replay          # the default for T = 1
+    e.graph_replay = False
+    assert not e.graph_replay
+    g.set_calibration(*dev)
+    e.set_calibration(*dev)
+    sets = [inp["imgs"]] + [S.blob_frames(calib, c["W"], c["H"], c["J"], 90 + i)[0] for i in range(3)]
+    side = torch.cuda.Stream()
+    outs = []
+    for i, f in enumerate(sets + sets[:1]):
+        x = cuda(f).unsqueeze(0).clone()              # a new tensor (pointer) per call
+        if i == 2:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                got = [t.clone() for t in g.forward(x)]
+            side.synchronize()
+        else:
+            got = [t.clone() for t in g.forward(x)]
+        ref = [t.clone() for t in e.forward(x)]
+        torch.cuda.synchronize()
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b), i
+        outs.append(got[0])
+    assert torch.equal(outs[0], outs[-1]) and max_err(outs[0], outs[1]) > 1e-2
+    # uint8 frames: a second graph of the same predictor
+    u8 = cuda((sets[1].permute(0, 2, 3, 1)[..., [2, 1, 0]] * 255).round().to(torch.uint8)).unsqueeze(0)
+    for _ in range(2):
+        a, b = g.forward(u8.clone()), e.forward(u8)
+        torch.cuda.synchronize()
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+    # new calibration VALUES reach the replayed graph (it reads the predictor's own copy)
+    other = [cuda(t) for t in S.ring_calibration(c["C"], c["W"], c["H"], 905.0)]
+    g.set_calibration(*other)
+    e.set_calibration(*other)
+    x = cuda(sets[0]).unsqueeze(0)
+    a, b = g.forward(x), e.forward(x)
+    torch.cuda.synchronize()
+    assert all(torch.equal(p, q) for p, q in zip(a, b)) and max_err(a[0], outs[0]) > 1e-2
+    # the integer path of the replayed call is readable as before
+    dbg = g.debug("cuda")
+    assert int(dbg["center3d_int"].abs().sum()) > 0
