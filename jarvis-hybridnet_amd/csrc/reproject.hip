@@ -255,6 +255,356 @@ __global__ __launch_bounds__(256) void repro_gather_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Cube form of the gather (round 3).  The gather above reads 16 bytes per lane straight from the
+// heatmaps: 302 MB of logical L1 traffic per frame in (voxel, camera)-scattered 96-byte segments,
+// with the per-camera chain LDS -> index -> gather exposed on every camera (0.93 ms per 32 frames,
+// 18 % of HBM).  Here a workgroup owns a CI x 16 x 16 cube of fine voxels and walks the cameras;
+// per camera
+//   * the bounding box of the cube's projection comes from the 8 corner nodes of the coarse (u, v)
+//     field that encloses the cube (a pinhole projection is monotone along lines, so the extremes
+//     over the cube sit at corners; one pixel of margin for the rounding of the interpolation),
+//   * the pixels inside it -- whole rows of the channel-last heatmap, i.e. fully coalesced 16-byte
+//     loads -- are staged ONCE in LDS and every tap is Q ds_read_b128 of the lane's OWN voxel (no
+//     cross-lane index shuffle): the 2.5 .. 5 uses a staged pixel sees inside one cube come out of
+//     LDS instead of L1.  A staged pixel takes Q + 1 sixteen-byte slots and a row an odd number of
+//     pixels, so the start banks of 16 neighbouring pixels -- along x or along y -- are all
+//     different and the 16 lanes of one LDS pass do not collide,
+//   * the patch of camera c+1 is in flight -- global_load_lds straight into the second patch
+//     buffer, no staging registers -- and the indices of camera c+1 are being interpolated while
+//     camera c is gathered: one workgroup barrier per camera, no exposed round trip.
+// The integer index path is the one above, instruction for instruction (up2_axis, lerp_ref, the
+// truncating /2).  A tap that falls outside the staged patch (never seen; a non-monotone lens model
+// would be needed) or a patch larger than the LDS budget is read from global memory by that lane:
+// the result does not depend on the box, only the speed does.
+constexpr int kCubeJ = 16, kCubeK = 16, kTabJ = 10, kTabK = 10;
+constexpr int kGeoBytes = 64 * 16;                   // boxes of up to 64 cameras
+constexpr int kCubePatchOff(int ci) { return 2 * (ci / 2 + 2) * kTabJ * kTabK * 8 + 256 + kGeoBytes; }
+
+struct CubeArgs {
+  const float2* coarse;
+  const float* heat;
+  float* vol;
+  int* idx_out;
+  int C, G, hs, heat_pad, div255, patch_bytes;
+  HeatLayout lay;
+  int abl;       // JH_REPRO_ABL bit mask (timing experiments only): 1 no patch loads, 2 no LDS gather,
+                 // 4 no tap interpolation after camera 0, 8 no stores, 16 no table prefetch
+};
+
+template <int Q, int CI, int NT>
+__global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
+  constexpr int VPT = CI * 256 / NT;                // voxels per thread (groups of 4 j-rows x 16 k per wave)
+  constexpr int NI = CI / 2 + 2, NTAB = NI * kTabJ * kTabK;
+  constexpr int TPT = (NTAB + NT - 1) / NT;         // table entries staged per thread
+  constexpr int JPB = Q * 16;                       // bytes per heatmap pixel in memory
+  constexpr int SPX = Q + 1;                        // 16-byte slots per staged pixel in LDS
+  constexpr int NR = (80 * 1024) / (NT * 16);       // NT-slot rounds of one patch (budget: a.patch_bytes)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float2* ctab = reinterpret_cast<float2*>(smem);   // [2][NTAB] cube-local coarse (u, v) of two cameras
+  constexpr int kZeroOff = 2 * NTAB * 8;            // one all-zero pixel (the virtual border)
+  constexpr int kGeoOff = kZeroOff + 256;           // [C] int4 (x0, y0, pw, ph): the patch boxes of all cameras
+  constexpr int kPatchOff = kCubePatchOff(CI);
+  typedef float gf4 __attribute__((ext_vector_type(4)));
+
+  const BlockId bid = xcd_block();
+  const int t = bid.y, tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int G = a.G, Gh = G >> 1, C = a.C, hs = a.hs;
+  const int nck = G / kCubeK, ncj = G / kCubeJ;
+  const int cube = (int)bid.x;
+  const int ck = cube % nck, cj = (cube / nck) % ncj, ci = cube / (nck * ncj);
+  const int I0 = ci * CI, J0 = cj * kCubeJ, K0 = ck * kCubeK;
+  const int bi = I0 / 2 - 1, bj = J0 / 2 - 1, bk = K0 / 2 - 1;       // coarse index of local entry 0
+  const int Hh = hs - 2 + 2 * a.heat_pad;
+  const int plane_bytes = Hh * Hh * JPB;
+  const size_t nvox = (size_t)G * G * G, nvox_c = (size_t)Gh * Gh * Gh;
+  const float* heat_t = a.heat + (size_t)t * a.lay.frame_stride;
+
+  if (tid < JPB / 4) reinterpret_cast<float*>(smem + kZeroOff)[tid] = 0.f;
+
+  // ---- per-lane constants: the voxels this lane owns ---------------------------------------------
+  int cidx[VPT];                     // entry of p000 in the local table
+  float wi0[VPT], wi1[VPT], wj0[VPT], wj1[VPT], wk0, wk1;
+  {
+    int k0, k1;
+    up2_axis(K0 + (lane & 15), Gh, &k0, &k1, &wk0, &wk1);
+#pragma unroll
+    for (int g = 0; g < VPT; ++g) {
+      const int gi = w * VPT + g, il = gi >> 2, jl = ((gi & 3) << 2) + (lane >> 4);
+      int i0, i1, j0, j1;
+      up2_axis(I0 + il, Gh, &i0, &i1, &wi0[g], &wi1[g]);
+      up2_axis(J0 + jl, Gh, &j0, &j1, &wj0[g], &wj1[g]);
+      cidx[g] = ((i0 - bi) * kTabJ + (j0 - bj)) * kTabK + (k0 - bk);
+    }
+  }
+  // local table entries of this thread (staging role)
+  int ctab_src[TPT];
+#pragma unroll
+  for (int e = 0; e < TPT; ++e) {
+    const int n = min(e * NT + tid, NTAB - 1);
+    const int li = n / (kTabJ * kTabK), lj = (n / kTabK) % kTabJ, lk = n % kTabK;
+    ctab_src[e] = (min(max(bi + li, 0), Gh - 1) * Gh + min(max(bj + lj, 0), Gh - 1)) * Gh +
+                  min(max(bk + lk, 0), Gh - 1);
+  }
+  // min / max over the 8 lanes of a half row: xor 1, xor 2 (quad permutes), mirror of the half row
+  auto min8 = [](float x) __attribute__((always_inline)) {
+    x = fminf(x, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true)));
+    x = fminf(x, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xF, 0xF, true)));
+    return fminf(x, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x141, 0xF, 0xF, true)));
+  };
+  auto max8 = [](float x) __attribute__((always_inline)) {
+    x = fmaxf(x, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true)));
+    x = fmaxf(x, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xF, 0xF, true)));
+    return fmaxf(x, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x141, 0xF, 0xF, true)));
+  };
+  // ---- boxes of ALL cameras, once per cube (prologue; wave w takes cameras w, w + waves, ...): lane
+  // n & 7 interpolates the cube's n-th corner VOXEL from the coarse field in global memory (the field is
+  // piecewise trilinear and the projection monotone along lines: the extremes of (u, v) over the cube
+  // are at its corner voxels); padded-heatmap pixel = trunc(u / 2), stored pixel = that - 1 +
+  // heat_pad, one pixel of margin for the rounding of the interpolation
+  {
+    int i0, i1, j0, j1, k0, k1;
+    float ki0, ki1, kj0, kj1, kk0, kk1;
+    up2_axis(I0 + ((lane & 4) ? CI - 1 : 0), Gh, &i0, &i1, &ki0, &ki1);
+    up2_axis(J0 + ((lane & 2) ? kCubeJ - 1 : 0), Gh, &j0, &j1, &kj0, &kj1);
+    up2_axis(K0 + ((lane & 1) ? kCubeK - 1 : 0), Gh, &k0, &k1, &kk0, &kk1);
+    for (int c = w; c < C; c += NT / 64) {
+      const float2* cz = a.coarse + (size_t)(t * C + c) * nvox_c;
+      const float2 p000 = cz[(i0 * Gh + j0) * Gh + k0], p001 = cz[(i0 * Gh + j0) * Gh + k1];
+      const float2 p010 = cz[(i0 * Gh + j1) * Gh + k0], p011 = cz[(i0 * Gh + j1) * Gh + k1];
+      const float2 p100 = cz[(i1 * Gh + j0) * Gh + k0], p101 = cz[(i1 * Gh + j0) * Gh + k1];
+      const float2 p110 = cz[(i1 * Gh + j1) * Gh + k0], p111 = cz[(i1 * Gh + j1) * Gh + k1];
+      const float u00 = lerp_ref(p000.x, p001.x, kk0, kk1), u01 = lerp_ref(p010.x, p011.x, kk0, kk1);
+      const float u10 = lerp_ref(p100.x, p101.x, kk0, kk1), u11 = lerp_ref(p110.x, p111.x, kk0, kk1);
+      const float v00 = lerp_ref(p000.y, p001.y, kk0, kk1), v01 = lerp_ref(p010.y, p011.y, kk0, kk1);
+      const float v10 = lerp_ref(p100.y, p101.y, kk0, kk1), v11 = lerp_ref(p110.y, p111.y, kk0, kk1);
+      const float uu = lerp_ref(lerp_ref(u00, u01, kj0, kj1), lerp_ref(u10, u11, kj0, kj1), ki0, ki1);
+      const float vv = lerp_ref(lerp_ref(v00, v01, kj0, kj1), lerp_ref(v10, v11, kj0, kj1), ki0, ki1);
+      const float ulo = min8(uu), uhi = max8(uu), vlo = min8(vv), vhi = max8(vv);
+      const int sh = -1 + a.heat_pad;
+      const int x0 = max((int)(ulo * 0.5f) + sh - 1, 0), y0 = max((int)(vlo * 0.5f) + sh - 1, 0);
+      const int x1 = min((int)(uhi * 0.5f) + sh + 1, Hh - 1), y1 = min((int)(vhi * 0.5f) + sh + 1, Hh - 1);
+      if (lane == 0)
+        *reinterpret_cast<int4*>(smem + kGeoOff + c * 16) = make_int4(x0, y0, max(x1 - x0 + 1, 1), max(y1 - y0 + 1, 1));
+    }
+  }
+
+  // patch geometry of one camera (uniform values): box origin, width, height, odd LDS row pitch
+  struct Geo { int x0, y0, pw, ph, pwp, slots, big; float rcp_spx_pwp; };
+  auto geometry = [&](int4 b) __attribute__((always_inline)) {
+    Geo g;
+    g.x0 = __builtin_amdgcn_readfirstlane(b.x); g.y0 = __builtin_amdgcn_readfirstlane(b.y);
+    g.pw = __builtin_amdgcn_readfirstlane(b.z); g.ph = __builtin_amdgcn_readfirstlane(b.w);
+    g.pwp = g.pw | 1;
+    g.slots = g.ph * g.pwp * SPX;                        // 16-byte LDS slots
+    g.big = g.slots * 16 > a.patch_bytes;
+    g.rcp_spx_pwp = 1.0f / (float)(g.pwp * SPX);
+    return g;
+  };
+  auto box = [&](int c) __attribute__((always_inline)) {
+    return *reinterpret_cast<const int4*>(smem + kGeoOff + min(c, C - 1) * 16);
+  };
+  auto cam_base = [&](int c) __attribute__((always_inline)) {
+    const int cblk = c / a.lay.cams_per_block, cloc = c - cblk * a.lay.cams_per_block;
+    return heat_t + (size_t)cblk * a.lay.block_stride + (size_t)cloc * (plane_bytes >> 2);
+  };
+  // where the taps of camera c (geometry g) of this lane's voxels are: an LDS byte offset (>= 0) or
+  // bit 31 + the byte offset inside the camera's heatmap (that lane then reads global memory)
+  auto tap_offsets = [&](int c, const Geo& g, int* off) __attribute__((always_inline)) {
+    const float2* cz = ctab + (c & 1) * NTAB;
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+      const float2* p = cz + cidx[v];
+      const float2 p000 = p[0], p001 = p[1];
+      const float2 p010 = p[kTabK], p011 = p[kTabK + 1];
+      const float2 p100 = p[kTabJ * kTabK], p101 = p[kTabJ * kTabK + 1];
+      const float2 p110 = p[kTabJ * kTabK + kTabK], p111 = p[kTabJ * kTabK + kTabK + 1];
+      const float u00 = lerp_ref(p000.x, p001.x, wk0, wk1), u01 = lerp_ref(p010.x, p011.x, wk0, wk1);
+      const float u10 = lerp_ref(p100.x, p101.x, wk0, wk1), u11 = lerp_ref(p110.x, p111.x, wk0, wk1);
+      const float v00 = lerp_ref(p000.y, p001.y, wk0, wk1), v01 = lerp_ref(p010.y, p011.y, wk0, wk1);
+      const float v10 = lerp_ref(p100.y, p101.y, wk0, wk1), v11 = lerp_ref(p110.y, p111.y, wk0, wk1);
+      const float u0 = lerp_ref(u00, u01, wj0[v], wj1[v]), u1 = lerp_ref(u10, u11, wj0[v], wj1[v]);
+      const float v0 = lerp_ref(v00, v01, wj0[v], wj1[v]), v1 = lerp_ref(v10, v11, wj0[v], wj1[v]);
+      const float uu = lerp_ref(u0, u1, wi0[v], wi1[v]);
+      const float vv = lerp_ref(v0, v1, wi0[v], wi1[v]);
+      const int iu = (int)__fdiv_rn(uu, 2.f), iv = (int)__fdiv_rn(vv, 2.f);
+      if (a.idx_out) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int gi = w * VPT + v, il = gi >> 2, jl = ((gi & 3) << 2) + (ln >> 4);
+        a.idx_out[((size_t)(t * C + c)) * nvox + ((size_t)(I0 + il) * G + (J0 + jl)) * G + K0 + (ln & 15)] =
+            iv * hs + iu;
+      }
+      const int hx = iu - 1 + a.heat_pad, hy = iv - 1 + a.heat_pad;
+      const int px = hx - g.x0, py = hy - g.y0;
+      int o = kZeroOff;                                                     // the (virtual) zero border
+      if (hx >= 0 && hy >= 0 && hx < Hh && hy < Hh) {
+        if (!g.big && px >= 0 && py >= 0 && px < g.pw && py < g.ph)
+          o = kPatchOff + (c & 1) * a.patch_bytes + (py * g.pwp + px) * (SPX * 16);
+        else
+          o = (int)0x80000000 | ((hy * Hh + hx) * JPB);
+      }
+      off[v] = o;
+      __builtin_amdgcn_sched_barrier(0);                 // one voxel at a time: register pressure
+    }
+  };
+  // patch of camera c -> LDS buffer c & 1.  LDS slot s (16 bytes) = quad s % SPX of staged pixel
+  // s / SPX (row-major, pitch pwp); global_load_lds writes at wave-uniform base + 16 * lane, so lane
+  // <-> slot; pad slots and slots past the end are masked off
+  auto load_patch = [&](int c, const Geo& g) __attribute__((always_inline)) {
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+    unsigned char* dst = smem + kPatchOff + (c & 1) * a.patch_bytes + (size_t)(tid & ~63) * 16;
+    const char* src = reinterpret_cast<const char*>(cam_base(c));
+#pragma nounroll
+    for (int r = 0; r < NR; ++r) {
+      if (r * NT < g.slots) {                                               // uniform
+        const int sl = r * NT + tid;
+        const int row = (int)(((float)sl + 0.5f) * g.rcp_spx_pwp);
+        const int rem = sl - row * (g.pwp * SPX);
+        const int px = rem / SPX, quad = rem - px * SPX;
+        if (sl < g.slots && quad < Q && px < g.pw)
+          __builtin_amdgcn_global_load_lds((glb_void*)(src + ((size_t)((g.y0 + row) * Hh + g.x0 + px)) * JPB + quad * 16),
+                                           (lds_void*)(dst + r * NT * 16), 16, 0, 0);
+      }
+    }
+  };
+
+  // ---- prologue: tables of cameras 0 and 1, taps and patch of camera 0 ----------------------------
+#pragma unroll
+  for (int e = 0; e < TPT; ++e)
+    if (e * NT + tid < NTAB) {
+      ctab[e * NT + tid] = a.coarse[(size_t)(t * C) * nvox_c + ctab_src[e]];
+      if (C > 1) ctab[NTAB + e * NT + tid] = a.coarse[(size_t)(t * C + 1) * nvox_c + ctab_src[e]];
+    }
+  __syncthreads();
+  Geo gc = geometry(box(0));
+  if (!gc.big) load_patch(0, gc);
+  int4 box_n = box(1);                                // (a box is fetched one camera ahead of its use)
+  int off_c[VPT];
+  tap_offsets(0, gc, off_c);
+  __syncthreads();
+
+  float4 acc[VPT][Q];
+#pragma unroll
+  for (int v = 0; v < VPT; ++v)
+#pragma unroll
+    for (int q = 0; q < Q; ++q) acc[v][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  for (int c = 0; c < ((a.abl & 32) ? 1 : C); ++c) {
+    // camera c+1: box, patch in flight into the other buffer; camera c+2: table entry in flight
+    Geo gn = gc;
+    const bool more = c + 1 < C;
+    if (more) {
+      if (!(a.abl & 64)) gn = geometry(box_n);
+      box_n = box(c + 2);
+      if (!gn.big && !(a.abl & 1)) load_patch(c + 1, gn);
+    }
+    float2 tv[TPT];
+#pragma unroll
+    for (int e = 0; e < TPT; ++e)
+      if (c + 2 < C && e * NT + tid < NTAB && !(a.abl & 16)) tv[e] = a.coarse[(size_t)(t * C + c + 2) * nvox_c + ctab_src[e]];
+    // gather camera c: every lane reads the Q quads of its own voxels' pixels
+    const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cam_base(c)), 0,
+                                                                           plane_bytes, 0x00020000);
+    if (!(a.abl & 2))
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+      const int o = off_c[v] >= 0 ? off_c[v] : kZeroOff;
+      gf4 h[Q];
+#pragma unroll
+      for (int q = 0; q < Q; ++q) h[q] = *reinterpret_cast<const gf4*>(smem + o + q * 16);
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        acc[v][q].x += h[q][0]; acc[v][q].y += h[q][1]; acc[v][q].z += h[q][2]; acc[v][q].w += h[q][3];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // taps that are not in LDS (a box over the LDS budget; never seen otherwise): from global memory.
+    // Those lanes added the zero pixel above, so the camera order of the sum is unchanged.
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+      if (__builtin_amdgcn_ballot_w64(off_c[v] < 0) != 0) {                  // uniform per wave
+        if (off_c[v] < 0) {
+#pragma unroll
+          for (int q = 0; q < Q; ++q) {
+            const gf4 h = __builtin_bit_cast(gf4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                      rs_c, (off_c[v] & 0x7fffffff) + q * 16, 0, 0));
+            acc[v][q].x += h[0]; acc[v][q].y += h[1]; acc[v][q].z += h[2]; acc[v][q].w += h[3];
+          }
+        }
+      }
+    }
+    if (more && !(a.abl & 4)) tap_offsets(c + 1, gn, off_c);          // (reads table (c+1) & 1; off_c of camera c is spent)
+    // table of camera c+2 over the table of camera c (read for the last time one iteration ago)
+#pragma unroll
+    for (int e = 0; e < TPT; ++e)
+      if (c + 2 < C && e * NT + tid < NTAB) ctab[(c & 1) * NTAB + e * NT + tid] = tv[e];
+    // one barrier per camera: patch c+1 has landed (vmcnt) and is visible, table c+2 is visible, and
+    // nobody still reads patch c, whose buffer the next iteration's prefetch overwrites
+    if (!(a.abl & 128)) __syncthreads();
+    gc = gn;
+  }
+
+  // ---- mean over cameras, / 255 (see repro_gather_kernel); a lane stores its voxels' Jp channels ----
+  const float fc = (float)C;
+  const float rfc = __fdiv_rn(1.f, fc), r255 = __fdiv_rn(1.f, 255.f);
+  auto divc = [](float x, float cc, float rc) __attribute__((always_inline)) {
+    const float q = __fmul_rn(x, rc);
+    return __fmaf_rn(__fmaf_rn(-q, cc, x), rc, q);
+  };
+  // The results leave through LDS (the patch buffers are free now): a lane parks the Jp channels of
+  // its voxels, then the wave streams its VPT * 4 runs of 16 voxels -- 16 * Jp * 4 contiguous bytes
+  // each in the volume -- as fully coalesced 16-byte stores (a lane writing its own voxel's 96 bytes
+  // directly is a 16-byte store at a 96-byte stride: 6 half-empty transactions per voxel).
+  int lane_late = lane;                               // (opaque: keeps the epilogue's addresses out of the loop's live set)
+  asm volatile("" : "+v"(lane_late));
+  unsigned char* park = smem + kPatchOff + (size_t)w * (64 * JPB);           // this wave's region
+  constexpr int kRunChunks = 16 * Q;                  // 16-byte chunks per run of 16 voxels
+#pragma unroll
+  for (int v = 0; v < VPT; ++v) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      float4 r;
+      r.x = divc(acc[v][q].x, fc, rfc); r.y = divc(acc[v][q].y, fc, rfc);
+      r.z = divc(acc[v][q].z, fc, rfc); r.w = divc(acc[v][q].w, fc, rfc);
+      if (a.div255) {
+        r.x = divc(r.x, 255.f, r255); r.y = divc(r.y, 255.f, r255);
+        r.z = divc(r.z, 255.f, r255); r.w = divc(r.w, 255.f, r255);
+      }
+      // voxel `lane` of group v = run lane / 16 (a j-row), position lane % 16 inside the run
+      *reinterpret_cast<float4*>(park + (lane_late * Q + q) * 16) = r;
+    }
+    // (the same wave wrote and reads: the LDS operations of a wave complete in order, no barrier)
+    const int gi = w * VPT + v, il = gi >> 2;
+#pragma unroll
+    for (int n = 0; n < Q; ++n) {
+      const int ch = n * 64 + lane_late;              // chunk of this group's 64 * Q
+      const int run = ch / kRunChunks, within = ch - run * kRunChunks;
+      const int jl = ((gi & 3) << 2) + run;
+      const size_t vox0 = ((size_t)(I0 + il) * G + (J0 + jl)) * G + K0;
+      const float4 r = *reinterpret_cast<const float4*>(park + ch * 16);
+      if (!(a.abl & 8))
+        *reinterpret_cast<float4*>(a.vol + ((size_t)t * nvox + vox0) * (JPB / 4) + within * 4) = r;
+    }
+  }
+}
+
+template <int Q, int CI, int NT>
+static int launch_cube(const CubeArgs& a, int T, hipStream_t s) {
+  auto kern = repro_cube_kernel<Q, CI, NT>;
+  static bool big = false;
+  if (!big) {
+    JH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    big = true;
+  }
+  const int cubes = (a.G / CI) * (a.G / kCubeJ) * (a.G / kCubeK);
+  hipLaunchKernelGGL(kern, dim3(cubes, T), dim3(NT), (size_t)kCubePatchOff(CI) + 2 * a.patch_bytes, s, a);
+  JH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_reproject(const float* cam, const float* intr, const float* dist, const int* center3d,
                      const int* center_hm, const float* heat, float2* coarse, float* vol,
                      int* idx_out, int T, int C, int G, float spacing, int hs, int Jp,
@@ -274,6 +624,21 @@ int launch_reproject(const float* cam, const float* intr, const float* dist, con
   hipLaunchKernelGGL(repro_coarse_kernel, dim3((nvc + 255) / 256, C, T), dim3(256), 0, s, cal,
                      center3d, center_hm, coarse, C, Gh, spacing, hs);
   JH_CHECK_HIP(hipGetLastError());
+  // cube form: G a multiple of 16, at most 32 channels (JH_REPRO_CUBE=0: the voxel-row form below)
+  if (G % 16 == 0 && Jp <= 32 && JH_ENV_KNOB("JH_REPRO_CUBE") != 0) {
+    CubeArgs ca{coarse, heat, vol, idx_out, C, G, hs, heat_pad, div255, 0, lay, 0};
+    ca.abl = std::max(0, JH_ENV_KNOB("JH_REPRO_ABL"));
+    const int Q = Jp / 4;
+    ca.patch_bytes = ((160 * 1024 - kCubePatchOff(8)) / 2) & ~1023;     // two patch buffers
+    switch (Q) {
+      case 2: return launch_cube<2, 8, 1024>(ca, T, s);
+      case 4: return launch_cube<4, 8, 512>(ca, T, s);
+      case 6: return JH_ENV_KNOB("JH_REPRO_NT") == 512 ? launch_cube<6, 8, 512>(ca, T, s)
+                                                        : launch_cube<6, 8, 1024>(ca, T, s);
+      case 8: return launch_cube<8, 8, 512>(ca, T, s);
+      default: break;
+    }
+  }
   // one block = up to 256 consecutive voxels of ONE i-plane
   const int bpp = (G * G + 255) / 256;
   dim3 grid(G * bpp, T);
