@@ -37,6 +37,19 @@ extern "C" {
 const char* jh_last_error(void);
 int jh_abi_version(void);
 
+/* ---- precision mode of the networks / predictors CREATED from now on (process-wide switch).
+ * JH_PRECISION_F32 (default): fp32 products and accumulation everywhere, the mode every parity
+ * figure of this library is quoted in.  JH_PRECISION_BF16X3: the 3x3x3 stride-1 convolutions of
+ * V2V run on the bf16 matrix cores with each fp32 operand split into two bf16 terms (three
+ * MFMAs per product, fp32 accumulation; about 2^-16 relative per product) -- the labelled
+ * reduced-precision mode that stands where the reference has its half-precision TensorRT
+ * engines (jarvis/prediction/jarvis3D.py:93,107,122: enabled_precisions={torch.half}).
+ * Environment JH_PRECISION=bf16x3 sets the initial mode. */
+#define JH_PRECISION_F32 0
+#define JH_PRECISION_BF16X3 1
+int jh_set_precision(int mode);
+int jh_get_precision(void);
+
 /* ---- parameters: a state dict in the reference's .pth key layout ----------
  * Replaces torch.load + load_state_dict of jarvis/hybridnet/hybridnet.py:84-97
  * and jarvis/efficienttrack/efficienttrack.py:90-113 on the native side. */

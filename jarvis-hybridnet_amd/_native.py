@@ -51,6 +51,8 @@ def workspace(nbytes, device):
 _SIGS = {
     "jh_last_error": (c_char_p, []),
     "jh_abi_version": (c_int, []),
+    "jh_set_precision": (c_int, [c_int]),
+    "jh_get_precision": (c_int, []),
     "jh_params_create": (c_int, [ctypes.POINTER(c_void_p)]),
     "jh_params_set": (c_int, [c_void_p, c_char_p, c_void_p, c_int64]),
     "jh_params_destroy": (None, [c_void_p]),
@@ -137,6 +139,22 @@ def lib():
             raise RuntimeError("libjarvis_hip.so ABI version mismatch")
         _lib = handle
     return _lib
+
+
+PRECISIONS = {"f32": 0, "bf16x3": 1}
+
+
+def set_precision(mode):
+    """Precision mode of the native networks / predictors created from now on: "f32" (default, the
+    parity mode) or "bf16x3" (V2V's 3x3x3 convolutions on the bf16 matrix cores with split operands;
+    a separately labelled reduced-precision mode).  Returns the previous mode."""
+    prev = get_precision()
+    check(lib().jh_set_precision(PRECISIONS[mode]))
+    return prev
+
+
+def get_precision():
+    return {v: k for k, v in PRECISIONS.items()}[lib().jh_get_precision()]
 
 
 def check(rc):

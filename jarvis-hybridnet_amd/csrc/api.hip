@@ -132,6 +132,13 @@ extern "C" {
 const char* jh_last_error(void) { return g_err.c_str(); }
 int jh_abi_version(void) { return JH_ABI_VERSION; }
 
+int jh_set_precision(int mode) {
+  JH_REQUIRE(mode == JH_PRECISION_F32 || mode == JH_PRECISION_BF16X3, "unknown precision mode");
+  set_precision_mode(mode);
+  return 0;
+}
+int jh_get_precision(void) { return precision_mode(); }
+
 int jh_params_create(jh_params** out) {
   *out = new jh_params();
   return 0;
@@ -719,8 +726,11 @@ int jh_op_conv(int nd, int kind, int k, int stride, int pad, int cin, int cout,
   // the same choice the V2V plan makes: 3x3x3 stride-1 convs run as Winograd (JH_WINO=0: direct)
   bool wino = kind == 0 && nd == 3 && k == 3 && stride == 1 && pad == 1 && !gate_dev;
   if (const char* e = getenv("JH_WINO")) wino = wino && atoi(e) != 0;
+  const bool b3 = wino && precision_mode() == 1;         // the same choice the V2V plan makes
   ConvWeights cw;
-  if (wino) {
+  if (b3) {
+    if (pack_bf16x3_weights(cin, cout, w_host, b_host, &cw)) return 1;
+  } else if (wino) {
     if (pack_wino_weights(cin, cout, w_host, b_host, &cw)) return 1;
   } else {
     if (pack_conv_weights(desc, w_host, b_host, kind != 0, &cw)) return 1;
@@ -740,7 +750,8 @@ int jh_op_conv(int nd, int kind, int k, int stride, int pad, int cin, int cout,
                            cin * sizeof(float), n, hipMemcpyDeviceToDevice, s) != hipSuccess) { rc = 1; break; }
     }
     if ((rc = launch_to_channel_last(x_dev, x, s))) break;
-    if (wino) { if ((rc = launch_conv3d_wino(cw, x, y, stats, s, nullptr, wino_variant_from_env()))) break; }
+    if (b3) { if ((rc = launch_conv3d_bf16x3(cw, x, y, stats, s, nullptr))) break; }
+    else if (wino) { if ((rc = launch_conv3d_wino(cw, x, y, stats, s, nullptr, wino_variant_from_env()))) break; }
     else if ((rc = launch_conv(desc, cw, x, y, gate_p, stats, s))) break;
     if (norm_act >= 0 && (rc = launch_norm_apply(y, stats, 1e-5f, norm_act, nullptr, nullptr, y.p, nullptr, s))) break;
     if ((rc = launch_from_channel_last(y, y_dev, s))) break;

@@ -286,6 +286,14 @@ int pack_wino_weights(int cin, int cout, const float* w, const float* b, ConvWei
 int wino_variant_from_env();
 int launch_conv3d_wino(const ConvWeights& w, const Act& x, const Act& y, double* stats, hipStream_t s,
                        const InNorm* in, int variant = 4);
+// split-bf16 form of the same convolution (csrc/conv3d_bf16x3.hip; precision mode bf16x3)
+int pack_bf16x3_weights(int cin, int cout, const float* w, const float* b, ConvWeights* out);
+int launch_conv3d_bf16x3(const ConvWeights& w, const Act& x, const Act& y, double* stats, hipStream_t s,
+                         const InNorm* in);
+// Precision mode of plans BUILT from now on: 0 = fp32 everywhere (default, the parity mode),
+// 1 = bf16x3 for the layers that have a split-bf16 kernel.  Set by jh_set_precision().
+int precision_mode();
+void set_precision_mode(int m);
 // vector-ALU stem convolution 3 -> 16, k3 s2 p1 (csrc/stem.hip)
 void pack_stem_weights(const float* w_host, float* packed);
 int launch_stem_conv(const Act& x, const float* w_dev, const Act& y, double* stats, hipStream_t s);

@@ -67,6 +67,10 @@ int Plan::finish() {
   return alloc(reinterpret_cast<void**>(&arena_), arena_doubles_ * sizeof(double));
 }
 
+static int g_precision = [] { const char* e = getenv("JH_PRECISION"); return e && std::string(e) == "bf16x3" ? 1 : 0; }();
+int precision_mode() { return g_precision; }
+void set_precision_mode(int m) { g_precision = m; }
+
 int Plan::run(hipStream_t s) {
   if (launch_zero(arena_, arena_doubles_ * sizeof(double), s)) return 1;
   Profiler& pf = profiler();
@@ -106,8 +110,13 @@ int Plan::add_conv(const ParamMap& pm, const ConvDesc& d, const std::string& wke
   bool wino = d.nd == 3 && d.k == 3 && d.stride == 1 && d.ostride == 1 && !transposed && !gate;
   if (const char* e = getenv("JH_WINO")) wino = wino && atoi(e) != 0;      // (plan build time)
   const int wino_variant = wino ? wino_variant_from_env() : 0;
+  // precision mode bf16x3 (opt-in, jh_set_precision): the same layers on the bf16 matrix cores with
+  // split operands (csrc/conv3d_bf16x3.hip)
+  const bool b3 = wino && precision_mode() == 1;
   ConvWeights cw;
-  if (wino) {
+  if (b3) {
+    if (pack_bf16x3_weights(d.cin, d.cout, w, b, &cw)) return 1;
+  } else if (wino) {
     if (pack_wino_weights(d.cin, d.cout, w, b, &cw)) return 1;
   } else {
     if (pack_conv_weights(d, w, b, transposed, &cw)) return 1;
@@ -127,11 +136,12 @@ int Plan::add_conv(const ParamMap& pm, const ConvDesc& d, const std::string& wke
   const double bytes = 4.0 * ((double)x.N * x.pixels() * d.cin + opix * d.cout + (double)d.cin * d.cout * taps);
   char nm[96];
   snprintf(nm, sizeof nm, "conv%dd_k%ds%d%s_%dx%d@%d", d.nd, d.ostride > 1 ? (d.nd == 2 ? 4 : 2) : d.k,
-           d.ostride > 1 ? 2 : d.stride, d.ostride > 1 ? "T" : (wino ? "wino" : ""), d.cin, d.cout, y.W);
+           d.ostride > 1 ? 2 : d.stride, d.ostride > 1 ? "T" : (b3 ? "bf16x3" : (wino ? "wino" : "")), d.cin, d.cout, y.W);
   push(nm, flops, bytes,
-       [this, d, cw, x, y, gate, want_stats, off, in_stats_off, in_inv, in_act, wino, wino_variant](hipStream_t s) {
+       [this, d, cw, x, y, gate, want_stats, off, in_stats_off, in_inv, in_act, wino, wino_variant, b3](hipStream_t s) {
     InNorm in;
     if (in_stats_off >= 0) { in.stats = sc((size_t)in_stats_off); in.inv = in_inv; in.act = in_act; }
+    if (b3) return launch_conv3d_bf16x3(cw, x, y, want_stats ? sc(off) : nullptr, s, &in);
     if (wino) return launch_conv3d_wino(cw, x, y, want_stats ? sc(off) : nullptr, s, &in, wino_variant);
     return launch_conv(d, cw, x, y, gate, want_stats ? sc(off) : nullptr, s, &in);
   });
