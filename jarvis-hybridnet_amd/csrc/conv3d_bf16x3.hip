@@ -83,13 +83,12 @@ __global__ __launch_bounds__(256) void conv3d_bf16x3_kernel(B3Args a) {
 
   // A-operand addresses of this lane: row block rb = y row, row = x = lane & 15, K group g = lane >> 4:
   // tap (g >> 1) of the slice's pair, channels 8 (g & 1) .. + 7 of the chunk
+  // (row block and tap offsets are compile-time immediates of the LDS reads)
   const int g = lane >> 4;
-  int abase[TY][3];
+  int abase[4];        // [kind 0..2], [3]: both K-group pairs on the SAME tap (the last slice's phantom tap)
 #pragma unroll
-  for (int rb = 0; rb < TY; ++rb)
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-      abase[rb][k] = (((wave * PY + rb) * PX + (lane & 15)) + ((g >> 1) ? kind_delta(k) : 0)) * 32 + (g & 1) * 16;
+  for (int k = 0; k < 4; ++k)
+    abase[k] = (((wave * PY) * PX + (lane & 15)) + ((g >> 1) && k < 3 ? kind_delta(k) : 0)) * 32 + (g & 1) * 16;
 
   f32x4 acc[TY][NCB];
 #pragma unroll
@@ -128,32 +127,51 @@ __global__ __launch_bounds__(256) void conv3d_bf16x3_kernel(B3Args a) {
       *reinterpret_cast<bf16x4*>(smem + PLANE + pix * 32 + q * 8) = lo;
     }
     __syncthreads();
-    // ---- 14 slices x (TY x NCB) x 3 MFMAs ---------------------------------------------------------
+    // ---- 14 slices x (TY x NCB) x 3 MFMAs; operands one step ahead: the weights of slice s+1 are
+    // requested before the MFMAs of slice s, the A rows of row block rb+1 before those of rb ------------
     const int wchunk = chunk * NSLICE * a.ncbt * 2 * 1024;
-#pragma unroll
-    for (int s = 0; s < NSLICE; ++s) {
-      bf16x8 bh[NCB], bl[NCB];
+    bf16x8 bh[2][NCB], bl[2][NCB];
+    auto load_b = [&](int s, int buf) __attribute__((always_inline)) {
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) {
         const int so = wchunk + ((s * a.ncbt + nb0 + cb) * 2) * 1024;
-        bh[cb] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane * 16, so, 0));
-        bl[cb] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane * 16, so + 1024, 0));
+        bh[buf][cb] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane * 16, so, 0));
+        bl[buf][cb] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane * 16, so + 1024, 0));
       }
-      const int toff = tap_off(2 * s) * 32;
-      const int kind = pair_kind(s);
+    };
+    // A rows of step i = slice * TY + row block (compile-time addresses: tap pair, row block, plane)
+    bf16x8 ah[2], al[2];
+    auto load_a = [&](int i, int buf) __attribute__((always_inline)) {
+      const int s = i / TY, rb = i % TY;
+      // (last slice: its second tap does not exist -- zero weights; its K groups re-read tap 26, any
+      // FINITE values: one pixel further would leave the patch for uninitialised LDS, and 0 x NaN = NaN)
+      const int ab = abase[(2 * s + 1 < 27) ? pair_kind(s) : 3];
+      const int off = tap_off(2 * s) * 32 + rb * PX * 32;
+      ah[buf] = *reinterpret_cast<const bf16x8*>(smem + ab + off);
+      al[buf] = *reinterpret_cast<const bf16x8*>(smem + PLANE + ab + off);
+    };
+    load_b(0, 0);
+    load_a(0, 0);
+#pragma unroll
+    for (int s = 0; s < NSLICE; ++s) {
+      const int cur = s & 1;
+      if (s + 1 < NSLICE) load_b(s + 1, cur ^ 1);
+      __builtin_amdgcn_sched_barrier(0);               // the weight prefetch stays AHEAD of this slice's MFMAs
 #pragma unroll
       for (int rb = 0; rb < TY; ++rb) {
-        // (last slice: its second tap does not exist -- zero weights; its K groups re-read tap 26, any
-        // FINITE values: one pixel further would leave the patch for uninitialised LDS, and 0 x NaN = NaN)
-        const int ao = (2 * s + 1 < 27) ? abase[rb][kind] : abase[rb][0] - ((g >> 1) ? kind_delta(0) * 32 : 0);
-        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(smem + ao + toff);
-        const bf16x8 al = *reinterpret_cast<const bf16x8*>(smem + PLANE + ao + toff);
+        const int i = s * TY + rb;
+        if (i + 1 < NSLICE * TY) load_a(i + 1, (i + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);             // ... and the next A rows ahead of this block's
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) {
-          acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[cb], acc[rb][cb], 0, 0, 0);
-          acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[cb], acc[rb][cb], 0, 0, 0);
-          acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[cb], acc[rb][cb], 0, 0, 0);
-        }
+        for (int cb = 0; cb < NCB; ++cb)
+          acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i & 1], bh[cur][cb], acc[rb][cb], 0, 0, 0);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+          acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i & 1], bh[cur][cb], acc[rb][cb], 0, 0, 0);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+          acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i & 1], bl[cur][cb], acc[rb][cb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }

@@ -104,3 +104,45 @@ def test_predictor3d_bf16x3(tag, golden, bf16x3):
     assert not torch.equal(pts, p32), "the precision mode had no effect"
     assert ep < 1e-3, "3D keypoints must be within 1e-3 mm of the reference"
     assert ec < 1e-4
+
+
+def test_bf16x3_seed_sweep_vs_f32_mode(bf16x3):
+    """64 seeds of the cfg2 rig: bf16x3 against the fp32 mode of the same library (which the 64-seed
+    sweep of tests/test_hip_predictor.py ties to the oracle).  The two modes share everything up to the
+    V2V input, so validity, centre argmax, crop centres and the truncated 3D centre are the SAME kernels'
+    outputs (asserted equal); what the split changes is the V2V output, i.e. the 3D keypoints."""
+    from jarvis_hybridnet_amd import synthetic as S
+    from jarvis_hybridnet_amd._predictor import NativePredictor
+    N = bf16x3
+    c = cases.PREDICTOR_CASES["cfg2"]
+    inp = cases.predictor_inputs("cfg2")
+    calib = (inp["cam"], inp["intr"], inp["dist"])
+    T = 16
+    kw = dict(num_cameras=c["C"], num_joints=c["J"], center_size=c["center_size"], bbox=c["bbox"],
+              roi_cube_size=c["roi"], grid_spacing=c["spacing"], img_h=c["H"], img_w=c["W"],
+              mean=S.MEAN, std=S.STD, time_batch=T)
+    dev = [cuda(t) for t in calib]
+    pb = NativePredictor(inp["sd_center"], inp["sd_hybrid"], **kw)
+    N.set_precision("f32")
+    pf = NativePredictor(inp["sd_center"], inp["sd_hybrid"], **kw)
+    N.set_precision("bf16x3")
+    pb.set_calibration(*dev)
+    pf.set_calibration(*dev)
+    worst_p, worst_c, nvalid = 0.0, 0.0, 0
+    for s0 in range(1000, 1064, T):
+        frames = cuda(torch.stack([S.blob_frames(calib, c["W"], c["H"], c["J"], s)[0] for s in range(s0, s0 + T)]))
+        ob = [t.clone() for t in pb.forward(frames)]
+        db = {k: v.clone() for k, v in pb.debug("cuda").items()}
+        of = [t.clone() for t in pf.forward(frames)]
+        df = pf.debug("cuda")
+        torch.cuda.synchronize()
+        assert torch.equal(ob[2], of[2])
+        for k in ("det", "center3d", "center3d_int", "center_hm"):
+            assert torch.equal(db[k], df[k]), k
+        ok = ob[2].bool()
+        nvalid += int(ok.sum())
+        if bool(ok.any()):
+            worst_p = max(worst_p, (ob[0][ok] - of[0][ok]).abs().max().item())
+            worst_c = max(worst_c, (ob[1][ok] - of[1][ok]).abs().max().item())
+    report("bf16x3_seed_sweep", seeds=64, valid=nvalid, worst_points_mm_vs_f32_mode=worst_p, worst_conf=worst_c)
+    assert nvalid >= 48 and worst_p < 1e-3 and worst_c < 1e-4
