@@ -542,6 +542,27 @@ def main():
             line["parity_max_abs_mm_vs_reference_fixture"] = float(
                 np.abs(res[0][0][0].cpu().numpy() - gold[0]).max())
 
+    if rank == 0 and not sharded and T >= 3:
+        # ---- side check (outside the timed region): one frame set of the batch replaced by an empty (all
+        # zero) one must not disturb its neighbours (time-batch slots are independent instances).  Whether the
+        # empty set itself is reported invalid depends on the weights: with these random-init networks the
+        # centre heatmaps exceed the detection threshold on any input (the (None, None) path of
+        # jarvis3D.py:157,187-190 is pinned by the fixture case cfg2_none, whose weights are scaled for it).
+        try:
+            fr2 = fr.clone()
+            fr2[1].zero_()
+            chk = [t.clone() for t in pred.forward(fr2, None)]
+            base = [t.clone() for t in pred.forward(fr, None)]
+            torch.cuda.synchronize()
+            keep = [i for i in range(T) if i != 1]
+            line["invalid_frame_check"] = {
+                "valid_flag_of_empty_frame": int(chk[2][1].item()),
+                "other_frames_bit_equal": bool(torch.equal(chk[0][keep], base[0][keep]) and
+                                               torch.equal(chk[2][keep], base[2][keep]))}
+            del fr2, chk, base
+        except Exception as e:
+            line["invalid_frame_check"] = {"error": repr(e)[:200]}
+
     if rank == 0 and not sharded and not args.no_reduced_precision and N.get_precision() == "f32":
         # ---- separately labelled reduced-precision line (BASELINE configs[1] is worded "bf16"; the
         # reference's own fast path is half precision, jarvis3D.py:93,107,122): V2V's 3x3x3 convolutions

@@ -8,7 +8,8 @@ root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=$root/gpurun_out/pmc_$tag
 rm -rf /tmp/pmc_$tag; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$root"
-if ! rocprofv3 --kernel-trace --pmc $counters -d /tmp/pmc_$tag -- "$@" > "$out/run.log" 2>&1; then
+# (bounded: a counter group the tool cannot collect has been seen to hang its finaliser for 20 minutes)
+if ! timeout -k 10 ${PMC_TIMEOUT:-420} rocprofv3 --kernel-trace --pmc $counters -d /tmp/pmc_$tag -- "$@" > "$out/run.log" 2>&1; then
   echo "pmc_pass: rocprofv3 failed, see $out/run.log" >&2; tail -5 "$out/run.log" >&2; exit 1
 fi
 db=$(find /tmp/pmc_$tag -name "*.db" | head -1)

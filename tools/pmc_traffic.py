@@ -22,7 +22,7 @@ CSRC = os.path.join(ROOT, "jarvis-hybridnet_amd", "csrc")
 SPECS = {
     "conv3d_k3s1wino_46x46@32": ("%conv3d_wino_pw_kernel%", "most_dispatches"),
     "conv3d_k3s1wino_92x92@16": ("%conv3d_wino_pw_kernel%", "fewest_dispatches"),
-    "reproject_gather": ("%repro_gather_kernel%", "largest_grid"),
+    "reproject_gather": ("%repro_cube_kernel%", "largest_grid"),
     "bifpn_node_56x56@64": ("%bifpn_node_kernel%", "largest_grid"),
     "preprocess_resize": ("%preprocess_resize%", "largest_grid"),
 }
