@@ -369,7 +369,9 @@ int jh_predictor_create(const jh_params* center_params, const jh_params* hybrid_
     if (m.get(reinterpret_cast<void**>(&pr->frames_cell), 256)) return 1;
     if (m.get(reinterpret_cast<void**>(&pr->g_points), (size_t)T * pr->J * 3 * sizeof(float))) return 1;
     if (m.get(reinterpret_cast<void**>(&pr->g_conf), (size_t)T * pr->J * sizeof(float))) return 1;
-    JH_CHECK_HIP(hipStreamCreateWithFlags(&pr->gstream, hipStreamNonBlocking));
+    // (the capture stream itself is created on first use: HIP multiplexes streams onto a few hardware
+    // queues, and an idle extra stream per predictor was seen to put the caller's copy stream on the
+    // compute stream's queue -- the overlapped uint8 upload of bench.py fell from 1135 to 705 frames/s)
   } else {
     pr->use_graph = 0;
   }
@@ -382,7 +384,7 @@ void jh_predictor_destroy(jh_predictor* pr) { delete pr; }
 
 int jh_predictor_set_graph_replay(jh_predictor* pr, int on) {
   JH_REQUIRE(pr, "bad argument");
-  JH_REQUIRE(!on || pr->gstream, "graph replay needs a predictor that owns all cameras and CenterDetect");
+  JH_REQUIRE(!on || pr->frames_cell, "graph replay needs a predictor that owns all cameras and CenterDetect");
   pr->use_graph = on != 0;
   return 0;
 }
@@ -527,6 +529,7 @@ static int forward_graph(jh_predictor* pr, const void* frames_dev, int src_u8, f
   hipGraphExec_t& exec = pr->gexec[src_u8 ? 1 : 0];
   if (!exec) {
     hipGraph_t g = nullptr;
+    if (!pr->gstream) JH_CHECK_HIP(hipStreamCreateWithFlags(&pr->gstream, hipStreamNonBlocking));
     JH_CHECK_HIP(hipStreamBeginCapture(pr->gstream, hipStreamCaptureModeRelaxed));
     pr->cur_cell = pr->frames_cell;
     const int rc = forward_eager(pr, nullptr, src_u8, pr->g_points, pr->g_conf, nullptr, pr->gstream);
