@@ -729,9 +729,13 @@ int jh_op_conv(int nd, int kind, int k, int stride, int pad, int cin, int cout,
   // the same choice the V2V plan makes: 3x3x3 stride-1 convs run as Winograd (JH_WINO=0: direct)
   bool wino = kind == 0 && nd == 3 && k == 3 && stride == 1 && pad == 1 && !gate_dev;
   if (const char* e = getenv("JH_WINO")) wino = wino && atoi(e) != 0;
-  const bool b3 = wino && precision_mode() == 1;         // the same choice the V2V plan makes
+  const bool b3 = wino && precision_mode() == 1;         // the same choices the plans make
+  const bool d4b = kind == 1 && !b_host && norm_act < 0 && !gate_dev && precision_mode() == 1 &&
+                   deconv4_bf16x3_eligible(cout);
   ConvWeights cw;
-  if (b3) {
+  if (d4b) {
+    if (pack_deconv4_bf16x3_weights(cin, cout, w_host, &cw)) return 1;
+  } else if (b3) {
     if (pack_bf16x3_weights(cin, cout, w_host, b_host, &cw)) return 1;
   } else if (wino) {
     if (pack_wino_weights(cin, cout, w_host, b_host, &cw)) return 1;
@@ -753,7 +757,8 @@ int jh_op_conv(int nd, int kind, int k, int stride, int pad, int cin, int cout,
                            cin * sizeof(float), n, hipMemcpyDeviceToDevice, s) != hipSuccess) { rc = 1; break; }
     }
     if ((rc = launch_to_channel_last(x_dev, x, s))) break;
-    if (b3) { if ((rc = launch_conv3d_bf16x3(cw, x, y, stats, s, nullptr))) break; }
+    if (d4b) { if ((rc = launch_deconv4_bf16x3(cw, x, y, s, nullptr))) break; }
+    else if (b3) { if ((rc = launch_conv3d_bf16x3(cw, x, y, stats, s, nullptr))) break; }
     else if (wino) { if ((rc = launch_conv3d_wino(cw, x, y, stats, s, nullptr, wino_variant_from_env()))) break; }
     else if ((rc = launch_conv(desc, cw, x, y, gate_p, stats, s))) break;
     if (norm_act >= 0 && (rc = launch_norm_apply(y, stats, 1e-5f, norm_act, nullptr, nullptr, y.p, nullptr, s))) break;

@@ -290,6 +290,10 @@ int launch_conv3d_wino(const ConvWeights& w, const Act& x, const Act& y, double*
 int pack_bf16x3_weights(int cin, int cout, const float* w, const float* b, ConvWeights* out);
 int launch_conv3d_bf16x3(const ConvWeights& w, const Act& x, const Act& y, double* stats, hipStream_t s,
                          const InNorm* in);
+// ... and of the keypoint head's ConvTranspose2d k4 s2 p1 (csrc/deconv4_bf16x3.hip; no bias, no statistics)
+int pack_deconv4_bf16x3_weights(int cin, int cout, const float* w, ConvWeights* out);
+bool deconv4_bf16x3_eligible(int cout);
+int launch_deconv4_bf16x3(const ConvWeights& w, const Act& x, const Act& y, hipStream_t s, const InNorm* in);
 // Precision mode of plans BUILT from now on: 0 = fp32 everywhere (default, the parity mode),
 // 1 = bf16x3 for the layers that have a split-bf16 kernel.  Set by jh_set_precision().
 int precision_mode();

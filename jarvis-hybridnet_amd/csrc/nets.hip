@@ -113,8 +113,13 @@ int Plan::add_conv(const ParamMap& pm, const ConvDesc& d, const std::string& wke
   // precision mode bf16x3 (opt-in, jh_set_precision): the same layers on the bf16 matrix cores with
   // split operands (csrc/conv3d_bf16x3.hip)
   const bool b3 = wino && precision_mode() == 1;
+  // ... and the keypoint head's ConvTranspose2d (no bias, no fused statistics, no gate)
+  const bool d4b = d.nd == 2 && d.ostride > 1 && transposed && !b && !want_stats && !gate &&
+                   precision_mode() == 1 && deconv4_bf16x3_eligible(d.cout);
   ConvWeights cw;
-  if (b3) {
+  if (d4b) {
+    if (pack_deconv4_bf16x3_weights(d.cin, d.cout, w, &cw)) return 1;
+  } else if (b3) {
     if (pack_bf16x3_weights(d.cin, d.cout, w, b, &cw)) return 1;
   } else if (wino) {
     if (pack_wino_weights(d.cin, d.cout, w, b, &cw)) return 1;
@@ -136,11 +141,12 @@ int Plan::add_conv(const ParamMap& pm, const ConvDesc& d, const std::string& wke
   const double bytes = 4.0 * ((double)x.N * x.pixels() * d.cin + opix * d.cout + (double)d.cin * d.cout * taps);
   char nm[96];
   snprintf(nm, sizeof nm, "conv%dd_k%ds%d%s_%dx%d@%d", d.nd, d.ostride > 1 ? (d.nd == 2 ? 4 : 2) : d.k,
-           d.ostride > 1 ? 2 : d.stride, d.ostride > 1 ? "T" : (b3 ? "bf16x3" : (wino ? "wino" : "")), d.cin, d.cout, y.W);
+           d.ostride > 1 ? 2 : d.stride, d.ostride > 1 ? (d4b ? "Tbf16x3" : "T") : (b3 ? "bf16x3" : (wino ? "wino" : "")), d.cin, d.cout, y.W);
   push(nm, flops, bytes,
-       [this, d, cw, x, y, gate, want_stats, off, in_stats_off, in_inv, in_act, wino, wino_variant, b3](hipStream_t s) {
+       [this, d, cw, x, y, gate, want_stats, off, in_stats_off, in_inv, in_act, wino, wino_variant, b3, d4b](hipStream_t s) {
     InNorm in;
     if (in_stats_off >= 0) { in.stats = sc((size_t)in_stats_off); in.inv = in_inv; in.act = in_act; }
+    if (d4b) return launch_deconv4_bf16x3(cw, x, y, s, &in);
     if (b3) return launch_conv3d_bf16x3(cw, x, y, want_stats ? sc(off) : nullptr, s, &in);
     if (wino) return launch_conv3d_wino(cw, x, y, want_stats ? sc(off) : nullptr, s, &in, wino_variant);
     return launch_conv(d, cw, x, y, gate, want_stats ? sc(off) : nullptr, s, &in);

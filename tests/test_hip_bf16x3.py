@@ -45,6 +45,26 @@ def test_conv3d_bf16x3_vs_torch(cin, cout, D, H, W, norm_act, bf16x3):
     assert e < 5e-5
 
 
+@pytest.mark.parametrize("cin,cout,H,W,n", [(64, 23, 64, 64, 12), (64, 30, 20, 24, 2), (88, 23, 12, 12, 2),
+                                               (64, 12, 9, 21, 3), (160, 23, 8, 16, 2)])
+def test_deconv2d_bf16x3_vs_torch(cin, cout, H, W, n, bf16x3):
+    """The keypoint head's ConvTranspose2d(k4, s2, p1) (no bias, no norm after it) in bf16x3 mode
+    (csrc/deconv4_bf16x3.hip: one parity per wave from one staged patch) against torch; asymmetric
+    random weights catch tap / parity swaps, ragged sizes the tile edges."""
+    from tests.test_hip_ops import _conv
+    g = torch.Generator().manual_seed(8 + cin + H)
+    x = torch.randn(n, cin, H, W, generator=g)
+    w = torch.randn(cin, cout, 4, 4, generator=g) / (cin * 4) ** 0.5
+    y, ref = _conv(2, 1, 4, 2, 1, cin, cout, x, w, None, norm_act=-1)
+    e = rel_err(y, ref)
+    bf16x3.set_precision("f32")
+    y32, _ = _conv(2, 1, 4, 2, 1, cin, cout, x, w, None, norm_act=-1)
+    bf16x3.set_precision("bf16x3")
+    report("deconv2d_bf16x3", cin=cin, cout=cout, h=H, w=W, rel=e, rel_fp32_kernel=rel_err(y32, ref))
+    assert not torch.equal(y, y32), "the precision mode had no effect"
+    assert e < 5e-5
+
+
 @pytest.mark.parametrize("tag", ["j23_g48", "j23_g64"])
 def test_v2v_bf16x3(tag, golden, bf16x3):
     """V2VNet + soft-argmax tail in bf16x3 mode against the oracle and the reference's golden points."""
