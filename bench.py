@@ -596,6 +596,8 @@ def main():
                    "dtype": "bf16x3 (fp32 operands split into two bf16 terms, three bf16 MFMAs per product, fp32 "
                             "accumulation) for the 3x3x3 stride-1 convolutions of V2V; f32 everywhere else",
                    "parity_max_abs_mm_vs_f32_mode": (routs[0][0] - res[0][0]).abs().max().item(),
+                   # 3D MPJPE against the fp32 mode over the T frame sets of one time batch (mm)
+                   "mpjpe_mm_vs_f32_mode": (routs[0][0] - res[0][0]).norm(dim=-1).mean().item(),
                    "kernels": [{k: (round(v, 5) if isinstance(v, float) else v) for k, v in r.items()
                                 if k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms",
                                          "launches_per_step", "algorithmic_equiv")} for r in rk]}
