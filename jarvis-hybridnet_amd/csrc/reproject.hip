@@ -629,13 +629,16 @@ int launch_reproject(const float* cam, const float* intr, const float* dist, con
     CubeArgs ca{coarse, heat, vol, idx_out, C, G, hs, heat_pad, div255, 0, lay, 0};
     ca.abl = std::max(0, JH_ENV_KNOB("JH_REPRO_ABL"));
     const int Q = Jp / 4;
-    ca.patch_bytes = ((160 * 1024 - kCubePatchOff(8)) / 2) & ~1023;     // two patch buffers
+    ca.patch_bytes = ((160 * 1024 - kCubePatchOff(8)) / 2) & ~1023;     // two patch buffers (CI <= 8)
     switch (Q) {
       case 2: return launch_cube<2, 8, 1024>(ca, T, s);
       case 4: return launch_cube<4, 8, 512>(ca, T, s);
       case 6: return JH_ENV_KNOB("JH_REPRO_NT") == 512 ? launch_cube<6, 8, 512>(ca, T, s)
                                                         : launch_cube<6, 8, 1024>(ca, T, s);
-      case 8: return launch_cube<8, 8, 512>(ca, T, s);
+      // 32 channels: 4-voxel-thick cubes, one voxel per lane (configs[4]: 1.37 against 1.48 ms per 8 frames
+      // for the 8-thick cube on 512 threads, 1.52 for the voxel-row kernel)
+      case 8: return JH_ENV_KNOB("JH_REPRO_Q8") == 0 ? launch_cube<8, 8, 512>(ca, T, s)
+                                                     : launch_cube<8, 4, 1024>(ca, T, s);
       default: break;
     }
   }
