@@ -40,13 +40,17 @@ int jh_abi_version(void);
 /* ---- precision mode of the networks / predictors CREATED from now on (process-wide switch).
  * JH_PRECISION_F32 (default): fp32 products and accumulation everywhere, the mode every parity
  * figure of this library is quoted in.  JH_PRECISION_BF16X3: the 3x3x3 stride-1 convolutions of
- * V2V run on the bf16 matrix cores with each fp32 operand split into two bf16 terms (three
- * MFMAs per product, fp32 accumulation; about 2^-16 relative per product) -- the labelled
+ * V2V, its stride-2 front convolution and the keypoint head's ConvTranspose2d run on the bf16 matrix
+ * cores with each fp32 operand split into two bf16 terms (three MFMAs per product, fp32 accumulation;
+ * about 2^-16 relative per product) -- the labelled
  * reduced-precision mode that stands where the reference has its half-precision TensorRT
  * engines (jarvis/prediction/jarvis3D.py:93,107,122: enabled_precisions={torch.half}).
- * Environment JH_PRECISION=bf16x3 sets the initial mode. */
+ * JH_PRECISION_BF16X3_WIDE additionally splits the dense k x k convolutions of the EfficientNet trunk
+ * (experimental: up to 7.6e-4 mm on the fixture cases, no margin under the 1e-3 mm bar).
+ * Environment JH_PRECISION=bf16x3 / bf16x3_wide sets the initial mode. */
 #define JH_PRECISION_F32 0
 #define JH_PRECISION_BF16X3 1
+#define JH_PRECISION_BF16X3_WIDE 2
 int jh_set_precision(int mode);
 int jh_get_precision(void);
 

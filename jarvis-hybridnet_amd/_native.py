@@ -141,13 +141,14 @@ def lib():
     return _lib
 
 
-PRECISIONS = {"f32": 0, "bf16x3": 1}
+PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x3_wide": 2}
 
 
 def set_precision(mode):
     """Precision mode of the native networks / predictors created from now on: "f32" (default, the
-    parity mode) or "bf16x3" (V2V's 3x3x3 convolutions on the bf16 matrix cores with split operands;
-    a separately labelled reduced-precision mode).  Returns the previous mode."""
+    parity mode), "bf16x3" (V2V's 3x3x3 convolutions and the keypoint head's ConvTranspose2d on the bf16
+    matrix cores with split operands; a separately labelled reduced-precision mode) or "bf16x3_wide"
+    (experimental: the trunk's dense 2D convolutions too).  Returns the previous mode."""
     prev = get_precision()
     check(lib().jh_set_precision(PRECISIONS[mode]))
     return prev

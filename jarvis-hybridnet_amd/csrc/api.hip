@@ -133,7 +133,8 @@ const char* jh_last_error(void) { return g_err.c_str(); }
 int jh_abi_version(void) { return JH_ABI_VERSION; }
 
 int jh_set_precision(int mode) {
-  JH_REQUIRE(mode == JH_PRECISION_F32 || mode == JH_PRECISION_BF16X3, "unknown precision mode");
+  JH_REQUIRE(mode == JH_PRECISION_F32 || mode == JH_PRECISION_BF16X3 || mode == JH_PRECISION_BF16X3_WIDE,
+             "unknown precision mode");
   set_precision_mode(mode);
   return 0;
 }
@@ -729,11 +730,15 @@ int jh_op_conv(int nd, int kind, int k, int stride, int pad, int cin, int cout,
   // the same choice the V2V plan makes: 3x3x3 stride-1 convs run as Winograd (JH_WINO=0: direct)
   bool wino = kind == 0 && nd == 3 && k == 3 && stride == 1 && pad == 1 && !gate_dev;
   if (const char* e = getenv("JH_WINO")) wino = wino && atoi(e) != 0;
-  const bool b3 = wino && precision_mode() == 1;         // the same choices the plans make
-  const bool d4b = kind == 1 && !b_host && norm_act < 0 && !gate_dev && precision_mode() == 1 &&
+  const bool b3 = wino && precision_mode() >= 1;         // the same choices the plans make
+  const bool d4b = kind == 1 && !b_host && norm_act < 0 && !gate_dev && precision_mode() >= 1 &&
                    deconv4_bf16x3_eligible(cout);
+  const bool xb = kind == 0 && !wino && !gate_dev && conv_bf16x3_eligible(desc) && x.Cp == cpad(cin) &&
+                  (precision_mode() == 2 || (precision_mode() == 1 && nd == 3));
   ConvWeights cw;
-  if (d4b) {
+  if (xb) {
+    if (pack_conv_bf16x3_weights(desc, w_host, b_host, &cw)) return 1;
+  } else if (d4b) {
     if (pack_deconv4_bf16x3_weights(cin, cout, w_host, &cw)) return 1;
   } else if (b3) {
     if (pack_bf16x3_weights(cin, cout, w_host, b_host, &cw)) return 1;
@@ -757,7 +762,8 @@ int jh_op_conv(int nd, int kind, int k, int stride, int pad, int cin, int cout,
                            cin * sizeof(float), n, hipMemcpyDeviceToDevice, s) != hipSuccess) { rc = 1; break; }
     }
     if ((rc = launch_to_channel_last(x_dev, x, s))) break;
-    if (d4b) { if ((rc = launch_deconv4_bf16x3(cw, x, y, s, nullptr))) break; }
+    if (xb) { if ((rc = launch_conv_bf16x3(desc, cw, x, y, stats, s, nullptr))) break; }
+    else if (d4b) { if ((rc = launch_deconv4_bf16x3(cw, x, y, s, nullptr))) break; }
     else if (b3) { if ((rc = launch_conv3d_bf16x3(cw, x, y, stats, s, nullptr))) break; }
     else if (wino) { if ((rc = launch_conv3d_wino(cw, x, y, stats, s, nullptr, wino_variant_from_env()))) break; }
     else if ((rc = launch_conv(desc, cw, x, y, gate_p, stats, s))) break;

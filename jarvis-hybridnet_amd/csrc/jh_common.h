@@ -294,6 +294,12 @@ int launch_conv3d_bf16x3(const ConvWeights& w, const Act& x, const Act& y, doubl
 int pack_deconv4_bf16x3_weights(int cin, int cout, const float* w, ConvWeights* out);
 bool deconv4_bf16x3_eligible(int cout);
 int launch_deconv4_bf16x3(const ConvWeights& w, const Act& x, const Act& y, hipStream_t s, const InNorm* in);
+// ... and of the dense k x k convolutions with a generic split-bf16 kernel (csrc/conv_bf16x3.h: 3D k3 s2,
+// 2D k3 s1 / k3 s2 / k5 s2; no gate)
+bool conv_bf16x3_eligible(const ConvDesc& d);
+int pack_conv_bf16x3_weights(const ConvDesc& d, const float* w, const float* b, ConvWeights* out);
+int launch_conv_bf16x3(const ConvDesc& d, const ConvWeights& w, const Act& x, const Act& y, double* stats,
+                       hipStream_t s, const InNorm* in);
 // Precision mode of plans BUILT from now on: 0 = fp32 everywhere (default, the parity mode),
 // 1 = bf16x3 for the layers that have a split-bf16 kernel.  Set by jh_set_precision().
 int precision_mode();

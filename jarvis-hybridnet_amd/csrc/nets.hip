@@ -67,7 +67,11 @@ int Plan::finish() {
   return alloc(reinterpret_cast<void**>(&arena_), arena_doubles_ * sizeof(double));
 }
 
-static int g_precision = [] { const char* e = getenv("JH_PRECISION"); return e && std::string(e) == "bf16x3" ? 1 : 0; }();
+static int g_precision = [] {
+  const char* e = getenv("JH_PRECISION");
+  if (!e) return 0;
+  return std::string(e) == "bf16x3" ? 1 : (std::string(e) == "bf16x3_wide" ? 2 : 0);
+}();
 int precision_mode() { return g_precision; }
 void set_precision_mode(int m) { g_precision = m; }
 
@@ -112,12 +116,21 @@ int Plan::add_conv(const ParamMap& pm, const ConvDesc& d, const std::string& wke
   const int wino_variant = wino ? wino_variant_from_env() : 0;
   // precision mode bf16x3 (opt-in, jh_set_precision): the same layers on the bf16 matrix cores with
   // split operands (csrc/conv3d_bf16x3.hip)
-  const bool b3 = wino && precision_mode() == 1;
+  const bool b3 = wino && precision_mode() >= 1;
   // ... and the keypoint head's ConvTranspose2d (no bias, no fused statistics, no gate)
   const bool d4b = d.nd == 2 && d.ostride > 1 && transposed && !b && !want_stats && !gate &&
-                   precision_mode() == 1 && deconv4_bf16x3_eligible(d.cout);
+                   precision_mode() >= 1 && deconv4_bf16x3_eligible(d.cout);
+  // ... and the dense k x k convolutions with a generic split-bf16 kernel (no gate; the 3-channel
+  // network input keeps its own kernels)
+  // Level 1 (bf16x3) takes the 3D one (V2V's stride-2 front convolution); the 2D trunk convolutions only
+  // at level 2 (bf16x3_wide): split, they move the keypoints by up to 7.6e-4 mm on the fixture cases, which
+  // leaves no margin under the 1e-3 mm bar.
+  const bool xb = !wino && !d4b && !transposed && !gate && conv_bf16x3_eligible(d) && x.Cp == cpad(d.cin) &&
+                  (precision_mode() == 2 || (precision_mode() == 1 && d.nd == 3));
   ConvWeights cw;
-  if (d4b) {
+  if (xb) {
+    if (pack_conv_bf16x3_weights(d, w, b, &cw)) return 1;
+  } else if (d4b) {
     if (pack_deconv4_bf16x3_weights(d.cin, d.cout, w, &cw)) return 1;
   } else if (b3) {
     if (pack_bf16x3_weights(d.cin, d.cout, w, b, &cw)) return 1;
@@ -141,11 +154,12 @@ int Plan::add_conv(const ParamMap& pm, const ConvDesc& d, const std::string& wke
   const double bytes = 4.0 * ((double)x.N * x.pixels() * d.cin + opix * d.cout + (double)d.cin * d.cout * taps);
   char nm[96];
   snprintf(nm, sizeof nm, "conv%dd_k%ds%d%s_%dx%d@%d", d.nd, d.ostride > 1 ? (d.nd == 2 ? 4 : 2) : d.k,
-           d.ostride > 1 ? 2 : d.stride, d.ostride > 1 ? (d4b ? "Tbf16x3" : "T") : (b3 ? "bf16x3" : (wino ? "wino" : "")), d.cin, d.cout, y.W);
+           d.ostride > 1 ? 2 : d.stride, d.ostride > 1 ? (d4b ? "Tbf16x3" : "T") : (b3 || xb ? "bf16x3" : (wino ? "wino" : "")), d.cin, d.cout, y.W);
   push(nm, flops, bytes,
-       [this, d, cw, x, y, gate, want_stats, off, in_stats_off, in_inv, in_act, wino, wino_variant, b3, d4b](hipStream_t s) {
+       [this, d, cw, x, y, gate, want_stats, off, in_stats_off, in_inv, in_act, wino, wino_variant, b3, d4b, xb](hipStream_t s) {
     InNorm in;
     if (in_stats_off >= 0) { in.stats = sc((size_t)in_stats_off); in.inv = in_inv; in.act = in_act; }
+    if (xb) return launch_conv_bf16x3(d, cw, x, y, want_stats ? sc(off) : nullptr, s, &in);
     if (d4b) return launch_deconv4_bf16x3(cw, x, y, s, &in);
     if (b3) return launch_conv3d_bf16x3(cw, x, y, want_stats ? sc(off) : nullptr, s, &in);
     if (wino) return launch_conv3d_wino(cw, x, y, want_stats ? sc(off) : nullptr, s, &in, wino_variant);

@@ -45,6 +45,33 @@ def test_conv3d_bf16x3_vs_torch(cin, cout, D, H, W, norm_act, bf16x3):
     assert e < 5e-5
 
 
+XCONV = [  # nd, k, stride, cin, cout, spatial, norm_act   (the layer shapes of the three model sizes + ragged ones)
+    (3, 3, 2, 23, 46, (24, 24, 24), 1), (3, 3, 2, 30, 60, (10, 14, 36), -1), (3, 3, 2, 12, 24, (8, 8, 8), 1),
+    (2, 3, 1, 16, 16, (32, 48), -1), (2, 3, 1, 40, 240, (16, 16), 2), (2, 3, 1, 32, 32, (20, 36), 2),
+    (2, 3, 2, 8, 48, (40, 40), 2), (2, 3, 2, 24, 144, (32, 32), 2), (2, 3, 2, 16, 96, (18, 34), -1),
+    (2, 5, 2, 16, 96, (32, 32), -1), (2, 5, 2, 24, 144, (20, 28), 2), (2, 5, 2, 40, 240, (16, 16), 2),
+]
+
+
+@pytest.mark.parametrize("nd,k,stride,cin,cout,shape,norm_act", XCONV)
+def test_conv_bf16x3_generic_vs_torch(nd, k, stride, cin, cout, shape, norm_act, bf16x3):
+    """The generic split-bf16 convolution (csrc/conv_bf16x3.h: 3D k3 s2, 2D k3 s1 / k3 s2 / k5 s2; stride 2
+    reads a de-interleaved patch) against torch fp32, incl. sizes that are not multiples of the tile."""
+    from tests.test_hip_ops import _conv
+    bf16x3.set_precision("bf16x3_wide")          # (the 2D forms belong to the wide level; the fixture restores)
+    g = torch.Generator().manual_seed(k * 10 + cin + shape[-1])
+    x = torch.randn(2, cin, *shape, generator=g)
+    w = torch.randn(cout, cin, *([k] * nd), generator=g) / (cin * k ** nd) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1 if nd == 3 else None
+    y, ref = _conv(nd, 0, k, stride, k // 2, cin, cout, x, w, b, norm_act=norm_act)
+    e = rel_err(y, ref)
+    bf16x3.set_precision("f32")
+    y32, _ = _conv(nd, 0, k, stride, k // 2, cin, cout, x, w, b, norm_act=norm_act)
+    report("conv_bf16x3_generic", nd=nd, k=k, stride=stride, cin=cin, cout=cout, rel=e, rel_fp32_kernel=rel_err(y32, ref))
+    assert not torch.equal(y, y32), "the precision mode had no effect"
+    assert e < 5e-5
+
+
 @pytest.mark.parametrize("cin,cout,H,W,n", [(64, 23, 64, 64, 12), (64, 30, 20, 24, 2), (88, 23, 12, 12, 2),
                                                (64, 12, 9, 21, 3), (160, 23, 8, 16, 2)])
 def test_deconv2d_bf16x3_vs_torch(cin, cout, H, W, n, bf16x3):
@@ -166,3 +193,27 @@ def test_bf16x3_seed_sweep_vs_f32_mode(bf16x3):
             worst_c = max(worst_c, (ob[1][ok] - of[1][ok]).abs().max().item())
     report("bf16x3_seed_sweep", seeds=64, valid=nvalid, worst_points_mm_vs_f32_mode=worst_p, worst_conf=worst_c)
     assert nvalid >= 48 and worst_p < 1e-3 and worst_c < 1e-4
+
+
+def test_predictor3d_bf16x3_wide(golden, bf16x3):
+    """Experimental level bf16x3_wide (the trunk's dense 2D convolutions split as well): measured against the
+    reference fixtures; it stays inside 1e-3 mm on them but without margin (7.6e-4 mm at cfg3), which is why it
+    is not the labelled mode.  Integer path still exact on the fixtures (top-2 margins >= 1 %)."""
+    from jarvis_hybridnet_amd.prediction.jarvis3D import JarvisPredictor3D
+    from tests.test_hip_predictor import make_cfg
+    bf16x3.set_precision("bf16x3_wide")
+    g = golden("predictor")
+    worst = 0.0
+    for tag in ("cfg2", "cfg3", "cfg5"):
+        c = cases.PREDICTOR_CASES[tag]
+        inp = cases.predictor_inputs(tag)
+        pred = JarvisPredictor3D(make_cfg(c, c["center_size"]), inp["sd_center"], inp["sd_hybrid"])
+        pts, conf = pred(cuda(inp["imgs"]), cuda(inp["cam"]), cuda(inp["intr"]), cuda(inp["dist"]))
+        torch.cuda.synchronize()
+        dbg = pred.native(c["H"], c["W"]).debug("cuda")
+        assert torch.equal(dbg["det"][0, :, :2].cpu().long(), torch.from_numpy(g[tag + ".preds"]).reshape(c["C"], 2))
+        assert torch.equal(dbg["center3d_int"][0].cpu(), torch.from_numpy(g[tag + ".center3d"]).int())
+        ep = max_err(pts, torch.from_numpy(g[tag + ".points3D"]))
+        report("predictor3d_bf16x3_wide", tag=tag, points_mm=ep)
+        worst = max(worst, ep)
+    assert worst < 2e-3
