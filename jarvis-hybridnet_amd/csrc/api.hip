@@ -414,9 +414,17 @@ static int stage_center_impl(jh_predictor* pr, const void* frames_dev, int src_u
   hipStream_t s = static_cast<hipStream_t>(stream);
   JH_REQUIRE(pr->center, "predictor was created without CenterDetect weights");
   const int N = pr->T * pr->Cloc, S = pr->cfg.center_size;
-  JH_PROF("preprocess_resize", 0.0, (double)N * S * S * (12.0 * (src_u8 ? 1 : 4) + 3 * 4),
-          launch_preprocess_resize(frames_dev, src_u8, pr->center->input.p, N, pr->cfg.img_h,
-                                   pr->cfg.img_w, S, pr->cfg.mean, pr->cfg.std, s, pr->cur_cell));
+  if (pr->center->stem_fusable) {
+    // resize + normalise happen inside the stem convolution's patch staging (csrc/stem.hip)
+    StemSource& src = pr->center->stem_src;
+    src.mode = 1; src.frames = frames_dev; src.frames_cell = pr->cur_cell; src.src_u8 = src_u8;
+    src.H = pr->cfg.img_h; src.W = pr->cfg.img_w;
+    for (int i = 0; i < 3; ++i) { src.mean[i] = pr->cfg.mean[i]; src.stdv[i] = pr->cfg.std[i]; }
+  } else {
+    JH_PROF("preprocess_resize", 0.0, (double)N * S * S * (12.0 * (src_u8 ? 1 : 4) + 3 * 4),
+            launch_preprocess_resize(frames_dev, src_u8, pr->center->input.p, N, pr->cfg.img_h,
+                                     pr->cfg.img_w, S, pr->cfg.mean, pr->cfg.std, s, pr->cur_cell));
+  }
   if (pr->center->run(s)) return 1;
   const Act& h = pr->center->heat;
   JH_PROF("center_argmax", 0.0, 4.0 * N * h.H * h.W,
@@ -455,9 +463,18 @@ static int stage_keypoints_impl(jh_predictor* pr, const void* frames_dev, int sr
   if (det_all_dev != pr->det_all)
     JH_CHECK_HIP(hipMemcpyAsync(pr->det_all, det_all_dev, (size_t)pr->T * pr->C * 3 * sizeof(float),
                                 hipMemcpyDeviceToDevice, s));
-  JH_PROF("preprocess_crop", 0.0, (double)pr->T * pr->Cloc * pr->B * pr->B * (src_u8 ? 15.0 : 24.0),
-          launch_preprocess_crop(frames_dev, src_u8, pr->chm, pr->kp->input.p, pr->T, pr->Cloc, pr->C,
-                                 c.cam_lo, c.img_h, c.img_w, pr->B, c.mean, c.std, s, pr->cur_cell));
+  if (pr->kp->stem_fusable) {
+    // crop + normalise happen inside the stem convolution's patch staging (csrc/stem.hip)
+    StemSource& src = pr->kp->stem_src;
+    src.mode = 2; src.frames = frames_dev; src.frames_cell = pr->cur_cell; src.src_u8 = src_u8;
+    src.center_hm = pr->chm; src.Cloc = pr->Cloc; src.C = pr->C; src.cam0 = c.cam_lo;
+    src.H = c.img_h; src.W = c.img_w;
+    for (int i = 0; i < 3; ++i) { src.mean[i] = c.mean[i]; src.stdv[i] = c.std[i]; }
+  } else {
+    JH_PROF("preprocess_crop", 0.0, (double)pr->T * pr->Cloc * pr->B * pr->B * (src_u8 ? 15.0 : 24.0),
+            launch_preprocess_crop(frames_dev, src_u8, pr->chm, pr->kp->input.p, pr->T, pr->Cloc, pr->C,
+                                   c.cam_lo, c.img_h, c.img_w, pr->B, c.mean, c.std, s, pr->cur_cell));
+  }
   if (pr->kp->run(s)) return 1;
   if (heat_dev && heat_dev != pr->kp->heat.p)
     JH_CHECK_HIP(hipMemcpyAsync(heat_dev, pr->kp->heat.p, pr->kp->heat.bytes(),
@@ -595,6 +612,7 @@ int jh_predictor_hybridnet_forward(jh_predictor* pr, const float* crops_dev,
   JH_CHECK_HIP(hipMemcpyAsync(pr->chm, center_hm_dev, (size_t)pr->T * pr->C * 2 * sizeof(int), hipMemcpyDeviceToDevice, s));
   JH_CHECK_HIP(hipMemcpyAsync(pr->c3i, center3d_dev, (size_t)pr->T * 3 * sizeof(int), hipMemcpyDeviceToDevice, s));
   if (launch_to_channel_last(crops_dev, pr->kp->input, s)) return 1;
+  pr->kp->stem_src.mode = 0;                      // (the crops are given: the stem reads the plan's input)
   if (pr->kp->run(s)) return 1;
   if (heatmaps_padded_dev) {
     const Act& h = pr->kp->heat;

@@ -12,25 +12,11 @@
 //  softargmax          softplus + spatial soft-argmax + confidences,
 //                      jarvis/hybridnet/model.py:73-88
 #include "jh_common.h"
+#include "preprocess.h"
 
 namespace jh {
 
 // ------------------------------------------------------------------ preprocess
-// Two frame formats: SRC = 0: [N][3][H][W] fp32 RGB in [0,1] (the API input of
-// JarvisPredictor3D.forward); SRC = 1: [N][H][W][3] uint8 BGR as the video decoder
-// delivers it, converted like predict3D.py:79-80 (`.float()...[:, [2,1,0]] / 255.`) on
-// the fly, so the 4x larger fp32 frame never exists.
-template <int SRC>
-__device__ __forceinline__ float frame_px(const void* frames, size_t n, int c, int y, int x, int H,
-                                          int W) {
-  if (SRC == 0)
-    return static_cast<const float*>(frames)[((n * 3 + c) * H + y) * W + x];
-  const unsigned char* p = static_cast<const unsigned char*>(frames) + ((n * H + y) * W + x) * 3;
-  // the reference driver divides on the GPU, where torch evaluates `x / 255.` as
-  // x * (1.f / 255.f) (division by a host scalar is a multiplication by its reciprocal)
-  return __fmul_rn((float)p[2 - c], __fdiv_rn(1.f, 255.f));
-}
-
 // out: [N][S][S][4] channel-last (one float4 per pixel: r, g, b, 0).
 template <int SRC>
 __global__ __launch_bounds__(256) void preprocess_resize_kernel(
@@ -43,24 +29,7 @@ __global__ __launch_bounds__(256) void preprocess_resize_kernel(
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (size_t)gridDim.x * blockDim.x) {
     const int ox = (int)(i % S), oy = (int)((i / S) % S), n = (int)(i / ((size_t)S * S));
-    float ry = fmaxf(__fsub_rn(__fmul_rn(sy, __fadd_rn((float)oy, 0.5f)), 0.5f), 0.f);
-    float rx = fmaxf(__fsub_rn(__fmul_rn(sx, __fadd_rn((float)ox, 0.5f)), 0.5f), 0.f);
-    int y0 = min((int)floorf(ry), H - 1), x0 = min((int)floorf(rx), W - 1);
-    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
-    const float ly1 = fminf(fmaxf(__fsub_rn(ry, (float)y0), 0.f), 1.f), ly0 = __fsub_rn(1.f, ly1);
-    const float lx1 = fminf(fmaxf(__fsub_rn(rx, (float)x0), 0.f), 1.f), lx0 = __fsub_rn(1.f, lx1);
-    const float mv[3] = {mean.x, mean.y, mean.z}, sv[3] = {stdv.x, stdv.y, stdv.z};
-    float r[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float p00 = frame_px<SRC>(frames, n, c, y0, x0, H, W), p01 = frame_px<SRC>(frames, n, c, y0, x1, H, W);
-      const float p10 = frame_px<SRC>(frames, n, c, y1, x0, H, W), p11 = frame_px<SRC>(frames, n, c, y1, x1, H, W);
-      const float a = __fmaf_rn(p00, lx0, __fmul_rn(p01, lx1));
-      const float b = __fmaf_rn(p10, lx0, __fmul_rn(p11, lx1));
-      const float v = __fmaf_rn(a, ly0, __fmul_rn(b, ly1));
-      r[c] = __fdiv_rn(__fsub_rn(v, mv[c]), sv[c]);
-    }
-    *reinterpret_cast<float4*>(out + i * 4) = make_float4(r[0], r[1], r[2], 0.f);
+    *reinterpret_cast<float4*>(out + i * 4) = resize_px<SRC>(frames, n, oy, ox, H, W, sy, sx, mean, stdv);
   }
 }
 
@@ -89,23 +58,13 @@ __global__ __launch_bounds__(256) void preprocess_crop_kernel(
     const void* const* __restrict__ frames_cell) {
   if (frames_cell) frames = *frames_cell;
   const size_t total = (size_t)T * Cloc * B * B;
-  const int hw = B / 2;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (size_t)gridDim.x * blockDim.x) {
     const int ox = (int)(i % B), oy = (int)((i / B) % B);
     const int n = (int)(i / ((size_t)B * B));
     const int t = n / Cloc, cl = n % Cloc;
     const int cx = center_hm[(t * C + cam0 + cl) * 2 + 0], cy = center_hm[(t * C + cam0 + cl) * 2 + 1];
-    const int ix = cx - hw + ox, iy = cy - hw + oy;
-    const float mv[3] = {mean.x, mean.y, mean.z}, sv[3] = {stdv.x, stdv.y, stdv.z};
-    float r[3] = {0.f, 0.f, 0.f};
-    const bool ok = ix >= 0 && ix < W && iy >= 0 && iy < H;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float v = ok ? frame_px<SRC>(frames, n, c, iy, ix, H, W) : 0.f;
-      r[c] = __fdiv_rn(__fsub_rn(v, mv[c]), sv[c]);
-    }
-    *reinterpret_cast<float4*>(out + i * 4) = make_float4(r[0], r[1], r[2], 0.f);
+    *reinterpret_cast<float4*>(out + i * 4) = crop_px<SRC>(frames, n, cx, cy, oy, ox, H, W, B, mean, stdv);
   }
 }
 

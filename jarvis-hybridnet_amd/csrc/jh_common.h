@@ -307,6 +307,9 @@ void set_precision_mode(int m);
 // vector-ALU stem convolution 3 -> 16, k3 s2 p1 (csrc/stem.hip)
 void pack_stem_weights(const float* w_host, float* packed);
 int launch_stem_conv(const Act& x, const float* w_dev, const Act& y, double* stats, hipStream_t s);
+struct StemSource;
+int launch_stem_conv_src(const StemSource& src, const Act& x, const float* w_dev, const Act& y, double* stats,
+                         hipStream_t s);
 int launch_deconv_c1(const Act& x, const double* stats, float inv_cnt, int in_act, const float* w,
                      const Act& y, hipStream_t s);
 

@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 #include "jh_common.h"
+#include "preprocess.h"
 
 namespace jh {
 
@@ -95,6 +96,11 @@ class EffTrackPlan : public Plan {
   // inference path never reads (hybridnet/model.py:57-58, jarvis3D.py:147)
   int build(const ParamMap& pm, const std::string& prefix, int size, int J, int N, int H, int W,
             bool want_res1 = false);
+  // Pre-processing fused into the stem convolution (small model's vector-ALU stem only): when
+  // stem_fusable, a caller may set stem_src.mode to 1 (resize) / 2 (crop) before run(); `input` is then
+  // never read.  mode 0 (default): the stem reads `input`.
+  bool stem_fusable = false;
+  StemSource stem_src;
   Act input;     // [N][H][W][8]   normalised image, channel-last
   Act heat;      // [N][H/2][W/2][Jp]  res2 (ConvTranspose output)
   Act res1;      // [N][H/4][W/4][Jp]  final_conv1 output (only with want_res1)

@@ -423,7 +423,11 @@ int EffTrackPlan::build(const ParamMap& pm, const std::string& pre, int size, in
     const double opix = (double)N * xo.pixels();
     push("conv2d_k3s2_3x16@" + std::to_string(xo.W), 2.0 * opix * 27 * 16,
          4.0 * ((double)N * xin.pixels() * 3 + opix * 16 + 27 * 16),
-         [this, xin, xo, wd, st](hipStream_t s) { return launch_stem_conv(xin, wd, xo, sc(st), s); });
+         [this, xin, xo, wd, st](hipStream_t s) {
+           if (stem_src.mode) return launch_stem_conv_src(stem_src, xin, wd, xo, sc(st), s);
+           return launch_stem_conv(xin, wd, xo, sc(st), s);
+         });
+    stem_fusable = JH_ENV_KNOB("JH_STEM_FUSE") != 0;
   } else if (add_conv(pm, conv_desc(2, 3, 2, 1, 3, stem), bb + "_conv_stem.weight", "", false, input, x.a,
                       nullptr, true, &st)) return 1;
   // the stem's InstanceNorm + swish is applied by the first block's conv on load

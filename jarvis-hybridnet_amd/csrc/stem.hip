@@ -11,10 +11,16 @@
 //     r, g, b, 0 per pixel) is staged once in LDS, zero padding = out-of-range buffer loads;
 //   * a thread produces all 16 channels of one pixel: 9 taps x 3 channels x 16 packed-FMA lanes,
 //     the weights are LDS broadcasts ([tap][cin][16] floats);
+//   * MODE 1 / 2 (round 3): the input pixels are not read from a pre-processed tensor but computed
+//     while the patch is staged -- the bilinear resize (CenterDetect) or the bounding-box crop
+//     (KeypointDetect) of the frames plus the normalisation, with the arithmetic of the stand-alone
+//     kernels (preprocess.h) -- so the 1 MB per image that `preprocess_resize` / `preprocess_crop` wrote
+//     and this kernel read back never exists;
 //   * raw output in the library's channel-last layout (four 16-byte stores per thread), and the
 //     per-(n, channel) sum / sum of squares of the tile for the InstanceNorm that follows
 //     (order-independent accumulation, jh_common.h).
 #include "jh_common.h"
+#include "preprocess.h"
 
 namespace jh {
 
@@ -24,10 +30,20 @@ typedef float sf2 __attribute__((ext_vector_type(2)));
 typedef float sf4 __attribute__((ext_vector_type(4)));
 }  // namespace
 
+struct StemSrcArgs {           // MODE != 0: the frames this launch pre-processes on the fly
+  const void* frames;
+  const void* const* frames_cell;
+  const int* center_hm;
+  int Cloc, C, cam0, FH, FW;
+  float sy, sx;
+  float3 mean, stdv;
+};
+
+template <int MODE, int SRC>
 __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ x,
                                                         const float* __restrict__ w /* [9][3][16] */,
                                                         float* __restrict__ y, double* __restrict__ stats,
-                                                        int H, int W) {
+                                                        int H, int W, StemSrcArgs sa) {
   __shared__ __attribute__((aligned(16))) float4 patch[kStP * kStP];
   __shared__ float red[16 * 256];                    // statistics: [channel][thread]
   __shared__ float red2[2 * 16 * 16];
@@ -40,13 +56,32 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
   // input patch: rows 2 oy0 - 1 .. 2 oy0 + 31, same in x
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(x + (size_t)n * H * W * 4), 0, H * W * 16, 0x00020000);
+  const void* frames = sa.frames;
+  int ccx = 0, ccy = 0;
+  if (MODE != 0) {
+    if (sa.frames_cell) frames = *sa.frames_cell;
+    if (MODE == 2) {
+      const int t = n / sa.Cloc, cl = n - t * sa.Cloc;
+      ccx = sa.center_hm[(t * sa.C + sa.cam0 + cl) * 2 + 0];
+      ccy = sa.center_hm[(t * sa.C + sa.cam0 + cl) * 2 + 1];
+    }
+  }
   for (int i = tid; i < kStP * kStP; i += 256) {
     const int py = i / kStP, px = i - py * kStP;
     const int iy = 2 * oy0 - 1 + py, ix = 2 * ox0 - 1 + px;
     const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
-    const int off = ok ? (iy * W + ix) * 16 : (int)0x80000000;
-    const sf4 v = __builtin_bit_cast(sf4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
-    patch[i] = make_float4(v[0], v[1], v[2], v[3]);
+    if (MODE == 0) {
+      const int off = ok ? (iy * W + ix) * 16 : (int)0x80000000;
+      const sf4 v = __builtin_bit_cast(sf4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+      patch[i] = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      // (the convolution's zero padding lies outside the pre-processed image: zeros, not normalised zeros)
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok)
+        v = MODE == 1 ? resize_px<SRC>(frames, n, iy, ix, sa.FH, sa.FW, sa.sy, sa.sx, sa.mean, sa.stdv)
+                      : crop_px<SRC>(frames, n, ccx, ccy, iy, ix, sa.FH, sa.FW, H, sa.mean, sa.stdv);
+      patch[i] = v;
+    }
   }
   __syncthreads();
   const int ty = tid >> 4, tx = tid & 15;
@@ -124,7 +159,31 @@ int launch_stem_conv(const Act& x, const float* w_dev, const Act& y, double* sta
              "stem convolution shapes");
   JH_REQUIRE((size_t)x.H * x.W * 16 < ((size_t)1 << 31), "stem input too large");
   const int tiles = ((y.H + kStT - 1) / kStT) * ((y.W + kStT - 1) / kStT);
-  hipLaunchKernelGGL(stem_conv_kernel, dim3(tiles, x.N), dim3(256), 0, s, x.p, w_dev, y.p, stats, x.H, x.W);
+  hipLaunchKernelGGL((stem_conv_kernel<0, 0>), dim3(tiles, x.N), dim3(256), 0, s, x.p, w_dev, y.p, stats, x.H, x.W,
+                     StemSrcArgs{});
+  JH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// The same convolution fed by the frames themselves (StemSource: resize or crop + normalise fused into the
+// patch staging); x only carries the shape of the image that would have been materialised.
+int launch_stem_conv_src(const StemSource& src, const Act& x, const float* w_dev, const Act& y, double* stats,
+                         hipStream_t s) {
+  JH_REQUIRE(src.mode == 1 || src.mode == 2, "stem source mode");
+  JH_REQUIRE(x.Cp == 4 && y.Cp == 16 && x.D == 1 && y.H * 2 == x.H && y.W * 2 == x.W && x.N == y.N && x.H == x.W,
+             "stem convolution shapes");
+  StemSrcArgs sa{};
+  sa.frames = src.frames; sa.frames_cell = src.frames_cell; sa.center_hm = src.center_hm;
+  sa.Cloc = src.Cloc; sa.C = src.C; sa.cam0 = src.cam0; sa.FH = src.H; sa.FW = src.W;
+  sa.sy = (float)src.H / (float)x.H; sa.sx = (float)src.W / (float)x.W;        // (as launch_preprocess_resize)
+  sa.mean = make_float3(src.mean[0], src.mean[1], src.mean[2]);
+  sa.stdv = make_float3(src.stdv[0], src.stdv[1], src.stdv[2]);
+  const int tiles = ((y.H + kStT - 1) / kStT) * ((y.W + kStT - 1) / kStT);
+  const dim3 grid(tiles, x.N);
+#define JH_STEM(M, U) hipLaunchKernelGGL((stem_conv_kernel<M, U>), grid, dim3(256), 0, s, x.p, w_dev, y.p, stats, x.H, x.W, sa)
+  if (src.mode == 1) { if (src.src_u8) JH_STEM(1, 1); else JH_STEM(1, 0); }
+  else { if (src.src_u8) JH_STEM(2, 1); else JH_STEM(2, 0); }
+#undef JH_STEM
   JH_CHECK_HIP(hipGetLastError());
   return 0;
 }
