@@ -50,11 +50,13 @@ __device__ __forceinline__ void block_channel_reduce(float4 s1, float4 s2, int n
 // ACT / R1 / R2 / Y are template parameters (the run-time form spent more scalar than vector
 // instructions on its per-element branches) and four pixels per thread are in flight at a time.
 // SiLU through v_exp_f32 / v_rcp_f32, as the convolutions apply it when they stage the same tensor.
-template <int ACT, bool R1, bool R2, bool Y>
+// R1N: the residual operand r1 is itself a raw tensor whose InstanceNorm + ReLU (statistics `stats1`) is
+// applied here, on load -- the V2V stage-entry tensors are then never materialised in normalised form.
+template <int ACT, bool R1, bool R2, bool Y, bool R1N = false>
 __global__ __launch_bounds__(256) void norm_apply_kernel(
     const float* __restrict__ x, const double* __restrict__ stats, float eps,
     const float* __restrict__ r1, const float* __restrict__ r2, float* __restrict__ y,
-    double* __restrict__ pool, int P, int Cp, int ppb) {
+    double* __restrict__ pool, int P, int Cp, int ppb, const double* __restrict__ stats1 = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int q = Cp >> 2;
   const int rows = 256 / q;
@@ -83,6 +85,24 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(
     }
     __syncthreads();                                     // (the pooled-sum reduce reuses nothing of mr, but
   }                                                      //  keeps the scratch layout simple)
+  float4 mean1 = make_float4(0, 0, 0, 0), rstd1 = make_float4(1, 1, 1, 1);
+  if (R1N) {
+    float* mr = sm + (pool ? rows * q * 4 : 0);
+    for (int c = tid; c < Cp; c += 256) {
+      const double* st = stats1 + ((size_t)n * Cp + c) * kStatW;
+      const double mu = exact_read(st) / (double)P;
+      double var = exact_read(st + kLimbs) / (double)P - mu * mu;
+      if (var < 0.0) var = 0.0;
+      mr[c] = (float)mu;
+      mr[Cp + c] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    if (active) {
+      mean1 = *reinterpret_cast<const float4*>(mr + c4 * 4);
+      rstd1 = *reinterpret_cast<const float4*>(mr + Cp + c4 * 4);
+    }
+    __syncthreads();
+  }
   const size_t base = (size_t)n * P * Cp + c4 * 4;
   const int p0 = blockIdx.x * ppb;
   const int p1 = min(P, p0 + ppb);
@@ -95,6 +115,10 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(
   auto finish = [&](float4 v, float4 a1, float4 a2, size_t off) __attribute__((always_inline)) {
     v.x = (v.x - mean.x) * rstd.x; v.y = (v.y - mean.y) * rstd.y;
     v.z = (v.z - mean.z) * rstd.z; v.w = (v.w - mean.w) * rstd.w;
+    if (R1N) {       // relu((r1 - mean1) * rstd1): the expression the stand-alone pass evaluates (ACT_RELU form above)
+      a1.x = fmaxf((a1.x - mean1.x) * rstd1.x, 0.f); a1.y = fmaxf((a1.y - mean1.y) * rstd1.y, 0.f);
+      a1.z = fmaxf((a1.z - mean1.z) * rstd1.z, 0.f); a1.w = fmaxf((a1.w - mean1.w) * rstd1.w, 0.f);
+    }
     if (R1) { v.x += a1.x; v.y += a1.y; v.z += a1.z; v.w += a1.w; }
     v.x = act1(v.x); v.y = act1(v.y); v.z = act1(v.z); v.w = act1(v.w);
     if (R2) { v.x += a2.x; v.y += a2.y; v.z += a2.z; v.w += a2.w; }
@@ -129,7 +153,7 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(
 }
 
 int launch_norm_apply(const Act& x, const double* stats, float eps, int act, const float* r1,
-                      const float* r2, float* y, double* pool, hipStream_t s) {
+                      const float* r2, float* y, double* pool, hipStream_t s, const double* r1_stats) {
   const int P = (int)x.pixels();
   const int q = x.Cp / 4;
   JH_REQUIRE(q >= 1 && q <= 256, "channel count out of range for norm_apply");
@@ -142,10 +166,21 @@ int launch_norm_apply(const Act& x, const double* stats, float eps, int act, con
   const int ppb = rows * iters;
   dim3 grid((P + ppb - 1) / ppb, x.N);
   const size_t sm = ((pool ? (size_t)rows * q * 4 : 0) + (stats ? (size_t)2 * x.Cp : 0)) * sizeof(float);
+  if (r1_stats) {     // residual operand normalised (+ReLU) on load: V2V residual blocks only
+    JH_REQUIRE(stats && r1 && y && act == ACT_RELU && !pool, "norm_apply: normalised residual operand");
+    if (r2)
+      hipLaunchKernelGGL((norm_apply_kernel<ACT_RELU, true, true, true, true>), grid, dim3(256), sm, s, x.p, stats, eps,
+                         r1, r2, y, pool, P, x.Cp, ppb, r1_stats);
+    else
+      hipLaunchKernelGGL((norm_apply_kernel<ACT_RELU, true, false, true, true>), grid, dim3(256), sm, s, x.p, stats, eps,
+                         r1, r2, y, pool, P, x.Cp, ppb, r1_stats);
+    JH_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
 #define JH_NA(A, B1, B2, BY)                                                                              \
   if (act == A && (r1 != nullptr) == B1 && (r2 != nullptr) == B2 && (y != nullptr) == BY) {             \
     hipLaunchKernelGGL((norm_apply_kernel<A, B1, B2, BY>), grid, dim3(256), sm, s, x.p, stats, eps, r1, r2, y, \
-                       pool, P, x.Cp, ppb);                                                               \
+                       pool, P, x.Cp, ppb, nullptr);                                                               \
     JH_CHECK_HIP(hipGetLastError());                                                                      \
     return 0;                                                                                             \
   }

@@ -172,9 +172,10 @@ ConvDesc deconv3d_k2s2_desc(int cin, int cout);
 // ---------------------------------------------------------------- elementwise
 // y = act((x - mean) * rstd + r1) + r2  with per-(n,c) statistics from `stats`
 // (biased variance, eps); optional pooled sum of y per (n,c) into `pool`.
+// r1_stats: r1 is a RAW tensor; its InstanceNorm + ReLU is applied on load (act must be ACT_RELU)
 int launch_norm_apply(const Act& x, const double* stats, float eps, int act,
                       const float* r1, const float* r2, float* y, double* pool,
-                      hipStream_t s);
+                      hipStream_t s, const double* r1_stats = nullptr);
 // squeeze-excite gate from pooled sums: gate[n][c] = sigmoid(We silu(Wr mean + br) + be)
 int launch_se_gate(const double* pool, int N, int C, int Cp, int S, float inv_hw,
                    const float* wr, const float* br, const float* we, const float* be,

@@ -77,7 +77,7 @@ class Plan {
                const float* gate, bool want_stats, size_t* stats_off, long in_stats_off = -1,
                float in_inv = 0.f, int in_act = 0);
   void add_norm(const Act& x, size_t stats_off, int act, const float* r1, const float* r2,
-                float* y, long pool_off);
+                float* y, long pool_off, long r1_stats_off = -1);
 };
 
 // A tensor as consumers see it: the raw conv output plus the statistics the
@@ -123,8 +123,9 @@ class V2VPlan : public Plan {
   Act output;    // [T][G/2]^3[Jp]
 
  private:
+  // x_stats >= 0: x is a raw conv output whose InstanceNorm + ReLU the block applies on load
   int res_block(const ParamMap& pm, const std::string& p, int c, const Act& x, const float* extra,
-                Act* out);
+                Act* out, long x_stats = -1);
 };
 
 }  // namespace jh

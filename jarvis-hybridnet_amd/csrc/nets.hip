@@ -169,12 +169,13 @@ int Plan::add_conv(const ParamMap& pm, const ConvDesc& d, const std::string& wke
 }
 
 void Plan::add_norm(const Act& x, size_t stats_off, int act, const float* r1, const float* r2,
-                    float* y, long pool_off) {
+                    float* y, long pool_off, long r1_stats_off) {
   const double el = (double)x.N * x.pixels() * x.C;
   push("norm_apply", 8.0 * el, 4.0 * el * (2 + (r1 ? 1 : 0) + (r2 ? 1 : 0)),
-       [this, x, stats_off, act, r1, r2, y, pool_off](hipStream_t s) {
+       [this, x, stats_off, act, r1, r2, y, pool_off, r1_stats_off](hipStream_t s) {
     return launch_norm_apply(x, sc(stats_off), 1e-5f, act, r1, r2, y,
-                             pool_off >= 0 ? sc((size_t)pool_off) : nullptr, s);
+                             pool_off >= 0 ? sc((size_t)pool_off) : nullptr, s,
+                             r1_stats_off >= 0 ? sc((size_t)r1_stats_off) : nullptr);
   });
 }
 
@@ -538,18 +539,19 @@ int EffTrackPlan::build(const ParamMap& pm, const std::string& pre, int size, in
 // Res3DBlock.forward, v2vnet.py:27-43: relu(IN(conv(relu(IN(conv(x))))) + x)
 // `extra`, when set, is added after the final relu (the encoder/decoder skip sum).
 int V2VPlan::res_block(const ParamMap& pm, const std::string& p, int c, const Act& x,
-                       const float* extra, Act* out) {
+                       const float* extra, Act* out, long x_stats) {
   Act a;
   if (new_act(x.N, x.D, x.H, x.W, c, &a)) return 1;
   size_t s1 = 0, s2 = 0;
+  const float inv = 1.f / (float)(x.D * x.H * x.W);
   if (add_conv(pm, conv_desc(3, 3, 1, 1, c, c), p + "res_branch.0.weight", p + "res_branch.0.bias",
-               false, x, a, nullptr, true, &s1)) return 1;
+               false, x, a, nullptr, true, &s1, x_stats, inv, ACT_RELU)) return 1;
   // the InstanceNorm + ReLU between the two convs is applied by the second conv on load
   if (new_act(x.N, x.D, x.H, x.W, c, out)) return 1;
   if (add_conv(pm, conv_desc(3, 3, 1, 1, c, c), p + "res_branch.3.weight", p + "res_branch.3.bias",
                false, a, *out, nullptr, true, &s2, (long)s1, 1.f / (float)(x.D * x.H * x.W),
                ACT_RELU)) return 1;
-  add_norm(*out, s2, ACT_RELU, x.p, extra, out->p, -1);
+  add_norm(*out, s2, ACT_RELU, x.p, extra, out->p, -1, x_stats);
   return 0;
 }
 
@@ -563,20 +565,24 @@ int V2VPlan::build(const ParamMap& pm, const std::string& pre, int J, int T, int
   if (new_act(T, Gh, Gh, Gh, 2 * J, &f0)) return 1;
   if (add_conv(pm, conv_desc(3, 3, 2, 1, J, 2 * J), pre + "front_layers.0.block.0.weight",
                pre + "front_layers.0.block.0.bias", false, input, f0, nullptr, true, &st)) return 1;
-  add_norm(f0, st, ACT_RELU, nullptr, nullptr, f0.p, -1);
-  if (res_block(pm, pre + "front_layers.1.", 2 * J, f0, nullptr, &f1)) return 1;
+  // The stage-entry tensors (f0, e0, u0) stay RAW: their InstanceNorm + ReLU is applied on load by the two
+  // readers, the residual block's first convolution and its closing relu(IN(conv2) + x) pass
+  // (JH_V2V_ENTRY_NORM=1: materialise them as rounds 1-2 did).
+  const bool lazy = JH_ENV_KNOB("JH_V2V_ENTRY_NORM") <= 0;
+  if (!lazy) add_norm(f0, st, ACT_RELU, nullptr, nullptr, f0.p, -1);
+  if (res_block(pm, pre + "front_layers.1.", 2 * J, f0, nullptr, &f1, lazy ? (long)st : -1)) return 1;
   const std::string e = pre + "encoder_decoder.";
   if (res_block(pm, e + "skip_res1.", 2 * J, f1, nullptr, &skip)) return 1;
   if (new_act(T, Gq, Gq, Gq, 4 * J, &e0)) return 1;
   if (add_conv(pm, conv_desc(3, 2, 2, 0, 2 * J, 4 * J), e + "encoder_pool1.block.0.weight",
                e + "encoder_pool1.block.0.bias", false, f1, e0, nullptr, true, &st)) return 1;
-  add_norm(e0, st, ACT_RELU, nullptr, nullptr, e0.p, -1);
-  if (res_block(pm, e + "mid_res.", 4 * J, e0, nullptr, &e1)) return 1;
+  if (!lazy) add_norm(e0, st, ACT_RELU, nullptr, nullptr, e0.p, -1);
+  if (res_block(pm, e + "mid_res.", 4 * J, e0, nullptr, &e1, lazy ? (long)st : -1)) return 1;
   if (new_act(T, Gh, Gh, Gh, 2 * J, &u0)) return 1;
   if (add_conv(pm, deconv3d_k2s2_desc(4 * J, 2 * J), e + "decoder_upsample1.block.0.weight",
                e + "decoder_upsample1.block.0.bias", true, e1, u0, nullptr, true, &st)) return 1;
-  add_norm(u0, st, ACT_RELU, nullptr, nullptr, u0.p, -1);
-  if (res_block(pm, e + "decoder_res1.", 2 * J, u0, skip.p, &d1)) return 1;   // ... + res1
+  if (!lazy) add_norm(u0, st, ACT_RELU, nullptr, nullptr, u0.p, -1);
+  if (res_block(pm, e + "decoder_res1.", 2 * J, u0, skip.p, &d1, lazy ? (long)st : -1)) return 1;   // ... + res1
   if (new_act(T, Gh, Gh, Gh, J, &output)) return 1;
   if (add_conv(pm, conv_desc(3, 1, 1, 0, 2 * J, J), pre + "output_layer.weight",
                pre + "output_layer.bias", false, d1, output, nullptr, false, nullptr)) return 1;
