@@ -137,7 +137,7 @@ static int pick_nr(int nb) {
 }
 
 int launch_conv(const ConvDesc& d, const ConvWeights& w, const Act& x, const Act& y,
-                const float* gate, double* stats, hipStream_t s, const InNorm* in) {
+                const float* gate, double* stats, hipStream_t s, const InNorm* in, const SeGate* se) {
   JH_REQUIRE(x.Cp == w.cin_p || (x.Cp == 4 && w.cin_p == 8), "conv input channel padding mismatch");
   JH_REQUIRE(y.Cp == cpad(d.cout), "conv output channel padding mismatch");
   JH_REQUIRE(x.N == y.N, "batch mismatch");
@@ -148,6 +148,11 @@ int launch_conv(const ConvDesc& d, const ConvWeights& w, const Act& x, const Act
     a.nrm_floats = 2 * w.cin_p;              // multiple of 16 floats
   }
   if (gate) a.nrm_floats += w.cin_p;            // the gate vector of the image, behind mean / rstd
+  if (se && se->pool) {                         // ... computed in the prologue: + channel means + hidden units
+    JH_REQUIRE(!gate, "either a gate tensor or a gate recipe");
+    a.se = *se;
+    a.nrm_floats += w.cin_p + round_up(se->C, 4) + round_up(se->S, 4);
+  }
   a.N = x.N; a.Din = x.D; a.Hin = x.H; a.Win = x.W; a.cin_p = w.cin_p; a.in_px = x.Cp;
   a.Dy = y.D; a.Hy = y.H; a.Wy = y.W; a.cout_p = y.Cp; a.cout_p16 = w.cout_p16;
   a.ostride = d.ostride; a.nphase = d.nphase; a.phase_stride = w.phase_stride; a.paired = w.paired;

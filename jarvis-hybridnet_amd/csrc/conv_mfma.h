@@ -231,8 +231,34 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 
   // the squeeze-excite gate of image n, behind mean / rstd (read while the patch is staged)
   float* gate_l = nrm + (a.in_stats ? 2 * a.cin_p : 0);
+  const bool gated = a.gate || a.se.pool;
   if (a.gate)
     for (int c = tid; c < a.cin_p; c += 256) gate_l[c] = a.gate[(size_t)n * a.cin_p + c];
+  if (a.se.pool) {
+    // the gate of image n from the pooled sums: the arithmetic of se_gate_kernel (elementwise.hip), term
+    // for term, so the fused and the stand-alone form give the same bits
+    const int C = a.se.C, S = a.se.S;
+    float* mean = gate_l + a.cin_p;
+    float* hid = mean + ((C + 3) & ~3);
+    for (int c = tid; c < C; c += 256)
+      mean[c] = (float)(exact_read(a.se.pool + ((size_t)n * a.cin_p + c) * kLimbs) * (double)a.se.inv_hw);
+    __syncthreads();
+    for (int j = tid; j < S; j += 256) {
+      float acc = a.se.br[j];
+      for (int c = 0; c < C; ++c) acc = fmaf(a.se.wr[j * C + c], mean[c], acc);
+      hid[j] = acc / (1.f + expf(-acc));
+    }
+    __syncthreads();
+    for (int c = tid; c < a.cin_p; c += 256) {
+      float g = 0.f;
+      if (c < C) {
+        float acc = a.se.be[c];
+        for (int j = 0; j < S; ++j) acc = fmaf(a.se.we[c * S + j], hid[j], acc);
+        g = 1.f / (1.f + expf(-acc));
+      }
+      gate_l[c] = g;
+    }
+  }
 
   const float* __restrict__ xin = a.x + (size_t)n * a.Din * a.Hin * a.Win * a.in_px;
   const int nkc8_total = a.cin_p >> 3;
@@ -327,7 +353,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         v.z = silu_fast(v.z); v.w = silu_fast(v.w);
       }
     }
-    if (a.gate) {
+    if (gated) {
       const float4 g = *reinterpret_cast<const float4*>(gate_l + c);
       v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w;
     }
@@ -368,7 +394,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
             mu0 = *reinterpret_cast<const float4*>(nrm + cc);
             rs0 = *reinterpret_cast<const float4*>(nrm + a.cin_p + cc);
           }
-          if (a.gate) gt0 = *reinterpret_cast<const float4*>(gate_l + cc);
+          if (gated) gt0 = *reinterpret_cast<const float4*>(gate_l + cc);
         }
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
@@ -382,7 +408,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
                 mu = *reinterpret_cast<const float4*>(nrm + cc);
                 rs = *reinterpret_cast<const float4*>(nrm + a.cin_p + cc);
               }
-              if (a.gate) gt = *reinterpret_cast<const float4*>(gate_l + cc);
+              if (gated) gt = *reinterpret_cast<const float4*>(gate_l + cc);
             }
             float4 v = pf[it];
             if (MODE != 0) {
@@ -398,7 +424,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
               }
               v.x *= m; v.y *= m; v.z *= m; v.w *= m;
             }
-            if (a.gate) { v.x *= gt.x; v.y *= gt.y; v.z *= gt.z; v.w *= gt.w; }
+            if (gated) { v.x *= gt.x; v.y *= gt.y; v.z *= gt.z; v.w *= gt.w; }
             float2* dst = lds2 + pix * S2 + c4 * 2;
             dst[0] = make_float2(v.x, v.y);
             dst[1] = make_float2(v.z, v.w);

@@ -122,12 +122,23 @@ inline FastDiv make_fastdiv(unsigned d) {
   return f;
 }
 
+// Squeeze-excite gate of an MBConv block computed by the CONSUMER (the project convolution) from the pooled
+// sums, instead of by a launch of its own: gate[c] = sigmoid(We silu(Wr mean + br) + be)
+// (jarvis/efficienttrack/efficientnet.py:107-112).  pool == nullptr: not used.
+struct SeGate {
+  const double* pool = nullptr;   // [N][cin_p][kLimbs] pooled sums of the activated tensor
+  const float *wr = nullptr, *br = nullptr, *we = nullptr, *be = nullptr;
+  int C = 0, S = 0;               // channels, squeeze width
+  float inv_hw = 0.f;
+};
+
 struct ConvArgs {
   const float* x;        // input activation
   float* y;              // output activation (raw, pre-norm)
   const float* w;        // packed weights
   const float* bias;     // [cout_p16] or nullptr
   const float* gate;     // [N][cin_p] multiplicative gate on the input or nullptr
+  SeGate se;             // ... or the recipe to compute it in the kernel's prologue
   const double* in_stats;  // [N][cin_p][2]: InstanceNorm (+ in_act) applied to the input on load
   float in_inv;            // 1 / pixels the input statistics were taken over
   int in_act;
@@ -161,7 +172,8 @@ struct InNorm {
   int act = 0;
 };
 int launch_conv(const ConvDesc& d, const ConvWeights& w, const Act& x, const Act& y,
-                const float* gate, double* stats, hipStream_t s, const InNorm* in = nullptr);
+                const float* gate, double* stats, hipStream_t s, const InNorm* in = nullptr,
+                const SeGate* se = nullptr);
 // output extent of a conv described by d for an input of extent (D,H,W)
 void conv_out_shape(const ConvDesc& d, int D, int H, int W, int* Do, int* Ho, int* Wo);
 

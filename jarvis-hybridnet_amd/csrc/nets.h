@@ -75,7 +75,7 @@ class Plan {
   int add_conv(const ParamMap& pm, const ConvDesc& d, const std::string& wkey,
                const std::string& bkey, bool transposed, const Act& x, const Act& y,
                const float* gate, bool want_stats, size_t* stats_off, long in_stats_off = -1,
-               float in_inv = 0.f, int in_act = 0);
+               float in_inv = 0.f, int in_act = 0, const SeGate* se = nullptr, long se_pool_off = -1);
   void add_norm(const Act& x, size_t stats_off, int act, const float* r1, const float* r2,
                 float* y, long pool_off, long r1_stats_off = -1);
 };

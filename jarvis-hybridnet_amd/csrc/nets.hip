@@ -103,7 +103,7 @@ int Plan::get(const ParamMap& pm, const std::string& key, size_t numel, const fl
 int Plan::add_conv(const ParamMap& pm, const ConvDesc& d, const std::string& wkey,
                    const std::string& bkey, bool transposed, const Act& x, const Act& y,
                    const float* gate, bool want_stats, size_t* stats_off, long in_stats_off,
-                   float in_inv, int in_act) {
+                   float in_inv, int in_act, const SeGate* se, long se_pool_off) {
   size_t taps;
   if (d.ostride > 1) taps = (d.nd == 2) ? 16 : 8;
   else taps = (size_t)d.k * d.k * (d.nd == 3 ? d.k : 1);
@@ -125,7 +125,7 @@ int Plan::add_conv(const ParamMap& pm, const ConvDesc& d, const std::string& wke
   // Level 1 (bf16x3) takes the 3D one (V2V's stride-2 front convolution); the 2D trunk convolutions only
   // at level 2 (bf16x3_wide): split, they move the keypoints by up to 7.6e-4 mm on the fixture cases, which
   // leaves no margin under the 1e-3 mm bar.
-  const bool xb = !wino && !d4b && !transposed && !gate && conv_bf16x3_eligible(d) && x.Cp == cpad(d.cin) &&
+  const bool xb = !wino && !d4b && !transposed && !gate && !se && conv_bf16x3_eligible(d) && x.Cp == cpad(d.cin) &&
                   (precision_mode() == 2 || (precision_mode() == 1 && d.nd == 3));
   ConvWeights cw;
   if (xb) {
@@ -156,14 +156,17 @@ int Plan::add_conv(const ParamMap& pm, const ConvDesc& d, const std::string& wke
   snprintf(nm, sizeof nm, "conv%dd_k%ds%d%s_%dx%d@%d", d.nd, d.ostride > 1 ? (d.nd == 2 ? 4 : 2) : d.k,
            d.ostride > 1 ? 2 : d.stride, d.ostride > 1 ? (d4b ? "Tbf16x3" : "T") : (b3 || xb ? "bf16x3" : (wino ? "wino" : "")), d.cin, d.cout, y.W);
   push(nm, flops, bytes,
-       [this, d, cw, x, y, gate, want_stats, off, in_stats_off, in_inv, in_act, wino, wino_variant, b3, d4b, xb](hipStream_t s) {
+       [this, d, cw, x, y, gate, want_stats, off, in_stats_off, in_inv, in_act, wino, wino_variant, b3, d4b, xb,
+        sev = se ? *se : SeGate(), se_pool_off](hipStream_t s) {
     InNorm in;
     if (in_stats_off >= 0) { in.stats = sc((size_t)in_stats_off); in.inv = in_inv; in.act = in_act; }
+    SeGate seg = sev;
+    if (se_pool_off >= 0) seg.pool = sc((size_t)se_pool_off);
     if (xb) return launch_conv_bf16x3(d, cw, x, y, want_stats ? sc(off) : nullptr, s, &in);
     if (d4b) return launch_deconv4_bf16x3(cw, x, y, s, &in);
     if (b3) return launch_conv3d_bf16x3(cw, x, y, want_stats ? sc(off) : nullptr, s, &in);
     if (wino) return launch_conv3d_wino(cw, x, y, want_stats ? sc(off) : nullptr, s, &in, wino_variant);
-    return launch_conv(d, cw, x, y, gate, want_stats ? sc(off) : nullptr, s, &in);
+    return launch_conv(d, cw, x, y, gate, want_stats ? sc(off) : nullptr, s, &in, se_pool_off >= 0 ? &seg : nullptr);
   });
   return 0;
 }
@@ -287,22 +290,35 @@ int EffTrackPlan::mbconv(const ParamMap& pm, const std::string& p, int stage, in
   if (get(pm, p + "_se_reduce.bias", squeeze, &br)) return 1;
   if (get(pm, p + "_se_expand.weight", (size_t)mid * squeeze, &we)) return 1;
   if (get(pm, p + "_se_expand.bias", mid, &be)) return 1;
-  float *dwr, *dbr, *dwe, *dbe, *gate;
+  float *dwr, *dbr, *dwe, *dbe, *gate = nullptr;
   if (upload(std::vector<float>(wr, wr + (size_t)squeeze * mid), &dwr)) return 1;
   if (upload(std::vector<float>(br, br + squeeze), &dbr)) return 1;
   if (upload(std::vector<float>(we, we + (size_t)mid * squeeze), &dwe)) return 1;
   if (upload(std::vector<float>(be, be + mid), &dbe)) return 1;
-  if (alloc(reinterpret_cast<void**>(&gate), (size_t)raw.N * raw.Cp * sizeof(float))) return 1;
   const float inv_hw = 1.f / (float)(Ho * Wo);
-  push("se_gate", 4.0 * raw.N * mid * squeeze, 8.0 * raw.N * mid,
-       [this, pool, raw, mid, squeeze, inv_hw, dwr, dbr, dwe, dbe, gate](hipStream_t s) {
-    return launch_se_gate(sc(pool), raw.N, mid, raw.Cp, squeeze, inv_hw, dwr, dbr, dwe, dbe, gate, s);
-  });
+  // Small batches (the single-frame-set call: 12 images, launch-latency-bound): the gate -- two tiny fully
+  // connected layers per image -- is computed by the project convolution's own prologue from the pooled
+  // sums, with the arithmetic of se_gate_kernel, bit for bit: 14 launches less per forward.  At bench
+  // scale the serial prologue in every project-conv workgroup costs more than the launches (1950-1969
+  // against 1973-1985 frames/s), so large batches keep the stand-alone se_gate launch.  JH_SE_FUSE=0 / 1
+  // forces either form.
+  const int se_knob = JH_ENV_KNOB("JH_SE_FUSE");
+  const bool se_fused = se_knob >= 0 ? se_knob != 0 : raw.N <= 32;
+  SeGate seg;
+  seg.wr = dwr; seg.br = dbr; seg.we = dwe; seg.be = dbe; seg.C = mid; seg.S = squeeze; seg.inv_hw = inv_hw;
+  if (!se_fused) {
+    if (alloc(reinterpret_cast<void**>(&gate), (size_t)raw.N * raw.Cp * sizeof(float))) return 1;
+    push("se_gate", 4.0 * raw.N * mid * squeeze, 8.0 * raw.N * mid,
+         [this, pool, raw, mid, squeeze, inv_hw, dwr, dbr, dwe, dbe, gate](hipStream_t s) {
+      return launch_se_gate(sc(pool), raw.N, mid, raw.Cp, squeeze, inv_hw, dwr, dbr, dwe, dbe, gate, s);
+    });
+  }
   // project (gate applied while staging the operand) + _gn2 (+ skip)
   if (new_act(x.N, 1, Ho, Wo, cout, out)) return 1;
   size_t st2 = 0;
   if (add_conv(pm, conv_desc(2, 1, 1, 0, mid, cout), p + "_project_conv.weight", "", false, raw,
-               *out, gate, true, &st2, (long)st1, 1.f / (float)(Ho * Wo), ACT_SILU)) return 1;
+               *out, gate, true, &st2, (long)st1, 1.f / (float)(Ho * Wo), ACT_SILU,
+               se_fused ? &seg : nullptr, se_fused ? (long)pool : -1)) return 1;
   if (skip) {
     add_norm(*out, st2, ACT_NONE, x.p, nullptr, out->p, -1);
     outr->st = -1;
