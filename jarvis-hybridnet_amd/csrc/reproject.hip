@@ -286,7 +286,8 @@ struct CubeArgs {
   const float* heat;
   float* vol;
   int* idx_out;
-  int C, G, hs, heat_pad, div255, patch_bytes;
+  int C, G, hs, heat_pad, div255, patch_bytes;   // patch_bytes: size of each of the two LDS patch buffers
+  int patch_limit;                               // largest box that is staged (<= patch_bytes; test knob)
   HeatLayout lay;
   int abl;       // JH_REPRO_ABL bit mask (timing experiments only): 1 no patch loads, 2 no LDS gather,
                  // 4 no tap interpolation after camera 0, 8 no stores, 16 no table prefetch
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
     g.pw = __builtin_amdgcn_readfirstlane(b.z); g.ph = __builtin_amdgcn_readfirstlane(b.w);
     g.pwp = g.pw | 1;
     g.slots = g.ph * g.pwp * SPX;                        // 16-byte LDS slots
-    g.big = g.slots * 16 > a.patch_bytes;
+    g.big = g.slots * 16 > a.patch_limit;
     g.rcp_spx_pwp = 1.0f / (float)(g.pwp * SPX);
     return g;
   };
@@ -626,10 +627,13 @@ int launch_reproject(const float* cam, const float* intr, const float* dist, con
   JH_CHECK_HIP(hipGetLastError());
   // cube form: G a multiple of 16, at most 32 channels (JH_REPRO_CUBE=0: the voxel-row form below)
   if (G % 16 == 0 && Jp <= 32 && JH_ENV_KNOB("JH_REPRO_CUBE") != 0) {
-    CubeArgs ca{coarse, heat, vol, idx_out, C, G, hs, heat_pad, div255, 0, lay, 0};
+    CubeArgs ca{coarse, heat, vol, idx_out, C, G, hs, heat_pad, div255, 0, 0, lay, 0};
     ca.abl = std::max(0, JH_ENV_KNOB("JH_REPRO_ABL"));
     const int Q = Jp / 4;
     ca.patch_bytes = ((160 * 1024 - kCubePatchOff(8)) / 2) & ~1023;     // two patch buffers (CI <= 8)
+    ca.patch_limit = ca.patch_bytes;
+    // (test knob: a smaller limit sends boxes to the per-lane global-memory path, which must give the same bits)
+    if (getenv("JH_REPRO_PATCH_KB")) ca.patch_limit = std::min(ca.patch_bytes, std::max(1, atoi(getenv("JH_REPRO_PATCH_KB"))) * 1024);
     switch (Q) {
       case 2: return launch_cube<2, 8, 1024>(ca, T, s);
       case 4: return launch_cube<4, 8, 512>(ca, T, s);

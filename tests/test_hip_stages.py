@@ -136,6 +136,27 @@ def test_reprojection(tag, golden):
     assert bad <= mism * J
 
 
+@pytest.mark.parametrize("kb", [1, 24])
+def test_reprojection_cube_global_fallback(kb, monkeypatch):
+    """The cube gather reads a tap from global memory when its camera's box does not fit the LDS budget (or
+    the tap lies outside the staged box).  No shipped geometry gets there, so the budget is shrunk here: 1 KB
+    sends every camera of every cube to that path, 24 KB a part of them; volume and indices must equal the
+    LDS-staged result bit for bit."""
+    from types import SimpleNamespace as NS
+    from jarvis_hybridnet_amd.hybridnet.repro_layer import ReprojectionLayer
+    C, J, G, spacing, bbox, W, H, focal, seed = cases.REPRO_CASES["cfg3"]
+    inp = cases.repro_inputs("cfg3")
+    cfg = NS(HYBRIDNET=NS(GRID_SPACING=spacing, ROI_CUBE_SIZE=G * spacing, NUM_CAMERAS=C),
+             KEYPOINTDETECT=NS(BOUNDING_BOX_SIZE=bbox))
+    layer = ReprojectionLayer(cfg)
+    args = [cuda(inp[k]) for k in ("hm_pad", "center3d", "center_hm", "cam", "intr", "dist")]
+    vol, idx = layer(*args).clone(), layer.gather_indices(*args).clone()
+    monkeypatch.setenv("JH_REPRO_PATCH_KB", str(kb))
+    vol2, idx2 = layer(*args), layer.gather_indices(*args)
+    torch.cuda.synchronize()
+    assert torch.equal(vol, vol2) and torch.equal(idx, idx2)
+
+
 @pytest.mark.parametrize("tag", ["c4", "c12"])
 def test_geometry(tag, golden):
     from jarvis_hybridnet_amd import synthetic as S
