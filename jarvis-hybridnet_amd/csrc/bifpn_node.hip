@@ -501,7 +501,11 @@ static int launch_node_variant(const NodeArgs& a, size_t lds, hipStream_t s) {
   return launch_node_one<NIN, M0, M1, M2, false>(a, lds, s);
 }
 
+bool bifpn_rows_eligible(const NodeArgs& a);
+int launch_bifpn_rows(const NodeArgs& a, hipStream_t s);
+
 int launch_bifpn_node(const NodeArgs& args, hipStream_t s) {
+  if (bifpn_rows_eligible(args)) return launch_bifpn_rows(args, s);      // csrc/bifpn_rows.hip
   NodeArgs a = args;
   if (JH_ENV_KNOB("JH_NODE_ABL") >= 0) a.abl = JH_ENV_KNOB("JH_NODE_ABL");   // timing experiments only
   const size_t head = ((size_t)3 * a.Cp * 2 + (size_t)9 * a.Cp) * sizeof(float);

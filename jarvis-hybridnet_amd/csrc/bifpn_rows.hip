@@ -1,0 +1,320 @@
+// Fused BiFPN node, row-streaming form (round 3) for the high-resolution levels of the 56-channel pyramid.
+//
+// Same function as bifpn_node.hip (fusion of 2-3 inputs with InstanceNorm on load, activation, depthwise
+// 3x3, pointwise 1x1 + bias, statistics of the output; jarvis/efficienttrack/model.py:309-353 + :223-232)
+// for the top-down nodes and the head (inputs: same level, x2, x4 up-sampled -- no max-pooled input).
+//
+// The tile kernel owns 8 x 16 pixels per 512-thread workgroup: 44-48 KB of LDS, three workgroups per CU, six
+// barriers per tile, 1.41 x halo overhead on the fusion work, and it is occupancy-bound (two workgroups per
+// CU: 505 us, three: 272 us at P3).  Here ONE WAVE owns a strip 16 pixels wide and walks it row by row:
+//   * a ring of three fused rows (18 pixels x 56 channels) in LDS is all the halo there is (1.125 x),
+//   * per output row: depthwise from the three ring rows -> 16 x 56 operand block -> 56 fp32 MFMAs against the
+//     pointwise weights, which stay in REGISTERS for the whole strip (56 VGPRs); the MFMAs take the weights as A
+//     and the pixels as B, so a lane ends up with four consecutive channels of one pixel: bias, statistics
+//     (per lane across the strip, reduced over the 16 pixel lanes once per strip) and one 16-byte channel-last
+//     store per column block, no transposes,
+//   * the raw inputs of row y+1 are requested as soon as row y is fused: a wave hides its own memory latency,
+//   * a workgroup is a single wave: no barriers at all; 18 KB of LDS, eight waves per CU (248 VGPRs),
+//   * everything that can be a per-lane constant is one (load offsets + scalar row offset, LDS addresses with
+//     immediate offsets, padding masks): the row loop is 480 instructions, 56 of them MFMAs.
+// The kernel is bound by instruction issue, not by memory (three inputs run as fast as two): per row and wave
+// 56 MFMAs x 32 cycles + ~100 packed FMAs + 40 exp / rcp + ~40 LDS and 14 memory instructions ~ 5 000 cycles,
+// which is what it measures (a SIMD issues one stream, times add).  P3 node of the bench
+// (384 images 64 x 64): 273.6 -> 216 us, head 304 -> 241 us.
+#include <type_traits>
+
+#include "conv_mfma.h"
+#include "bifpn_node.h"
+
+namespace jh {
+
+namespace {
+constexpr int kRC = 56, kRQ = kRC / 4, kRPX = 18, kRSA = kRC + 4;       // channels, quads, ring row width, A stride
+constexpr int kAFloats = 16 * kRSA;
+typedef float rf2 __attribute__((ext_vector_type(2)));
+typedef float rf4 __attribute__((ext_vector_type(4)));
+}  // namespace
+
+template <int NIN, int M1, int M2, int ACT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void bifpn_rows_kernel(const NodeArgs a, int seg_rows, int strips) {
+  constexpr int kModes[3] = {FUSE_SAME, M1, M2};
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // byte offsets inside the wave's LDS: ring of three fused rows, operand block, depthwise weights
+  constexpr int kRowB = kRPX * kRC * 4;           // 4032
+  constexpr int kAtOff = 3 * kRowB, kDwOff = kAtOff + kAFloats * 4, kBiasOff = kDwOff + 9 * kRC * 4;
+  const int lane = threadIdx.x;
+  const int q = lane % kRQ, sub = lane / kRQ;     // channel quad, pixel slot (0..3; 4 = idle lanes 56..63)
+  const bool act_lane = sub < 4;
+  const int c = q * 4;
+  const int sx = blockIdx.x % strips, seg = blockIdx.x / strips, n = blockIdx.y;
+  const int ox0 = sx * 16, y_begin = seg * seg_rows, y_end = min(a.H, y_begin + seg_rows);
+  const int mrow = lane & 15, kq = lane >> 4;
+
+  // ---- per-lane constants --------------------------------------------------------------------------------
+  // folded norm + fusion weights of this lane's channel quad: fused = sum_k x_k a_k + B
+  rf4 ak[NIN], bb = (rf4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < NIN; ++k) {
+    float m4[4] = {0.f, 0.f, 0.f, 0.f}, r4[4] = {1.f, 1.f, 1.f, 1.f};
+    if (a.st[k]) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const double* st = a.st[k] + ((size_t)n * kRC + c + j) * kStatW;
+        const double mu = exact_read(st) * (double)a.inv_cnt[k];
+        double var = exact_read(st + kLimbs) * (double)a.inv_cnt[k] - mu * mu;
+        if (var < 0.0) var = 0.0;
+        m4[j] = (float)mu;
+        r4[j] = (float)(1.0 / sqrt(var + 1e-5));
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float ak1 = a.w[k] * r4[j];
+      ak[k][j] = ak1;
+      bb[j] += -m4[j] * ak1;
+    }
+  }
+  // depthwise weights of this lane's channel quad: registers when the budget allows (two inputs), else LDS --
+  // every LDS instruction costs the SIMD about as much issue time as an MFMA
+  constexpr bool kDwReg = NIN == 2;
+  rf4 dwr[kDwReg ? 9 : 1];
+  if (kDwReg) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) dwr[t] = *reinterpret_cast<const rf4*>(a.dw + t * kRC + (act_lane ? c : 0));
+  } else {
+    for (int i = lane; i < 9 * kRC; i += 64) reinterpret_cast<float*>(smem + kDwOff)[i] = a.dw[i];
+  }
+  // pointwise weights of this lane for all 7 channel steps x 4 column blocks (registers for the whole strip);
+  // the MFMAs run with the operands swapped (weights as A, pixels as B), so the accumulator of column block cb
+  // holds, for pixel lane & 15, the four channels 16 cb + 4 (lane >> 4) .. + 3: one 16-byte store, no transposes
+  rf2 bw[kRC / 8][4];
+#pragma unroll
+  for (int k8 = 0; k8 < kRC / 8; ++k8)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+      bw[k8][cb] = *reinterpret_cast<const rf2*>(a.pw + ((size_t)(k8 * 4 + cb) * 64 + lane) * 2);
+  reinterpret_cast<float*>(smem + kBiasOff)[lane] = a.bias ? a.bias[lane] : 0.f;   // (bias: 64 floats, padded)
+
+  __amdgpu_buffer_rsrc_t rs[NIN];
+  int rowstep[NIN];                                // bytes per source row of input k
+#pragma unroll
+  for (int k = 0; k < NIN; ++k) {
+    const int sh = kModes[k] == FUSE_UP2 ? 1 : (kModes[k] == FUSE_UP4 ? 2 : 0);
+    const size_t plane = node_plane(kModes[k], a.H, a.W) * kRC;
+    rs[k] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in[k] + (size_t)n * plane), 0, (int)(plane * 4),
+                                              0x00020000);
+    rowstep[k] = (a.W >> sh) * kRC * 4;
+  }
+  // the 5 items of this lane in a fused row (pixel it * 4 + sub of the 18): load offsets inside a source row
+  // (bit 31 = outside the image: the buffer load returns 0) and the 0 / 1 mask of the depthwise zero padding
+  int voff[NIN][5];
+  float msk[5];
+#pragma unroll
+  for (int it = 0; it < 5; ++it) {
+    const int px = it * 4 + sub, ix = ox0 - 1 + px;
+    const bool ok = act_lane && px < kRPX && (unsigned)ix < (unsigned)a.W;
+    msk[it] = ok ? 1.f : 0.f;
+#pragma unroll
+    for (int k = 0; k < NIN; ++k) {
+      const int sh = kModes[k] == FUSE_UP2 ? 1 : (kModes[k] == FUSE_UP4 ? 2 : 0);
+      voff[k][it] = ok ? ((ix >> sh) * kRC + c) * 4 : (int)0x80000000;
+    }
+  }
+  const int fdst = (sub * kRC + c) * 4;                         // + it * 4 pixels (imm) + ring slot
+  const int dsrc = (sub * 4 * kRC + c) * 4;                     // + ring slot + tap (imm)
+  const int adst = kAtOff + (sub * 4 * kRSA + c) * 4;           // + pixel (imm)
+  const int ard = kAtOff + (mrow * kRSA) * 4 + kq * 8;          // + channel step (imm)
+  float* const ybase = a.y + ((size_t)n * a.H * a.W + ox0 + mrow) * a.cout_p + kq * 4;
+
+  // Raw rows in flight: DEPTH register sets (2 for two inputs: the loads of row yf + 2 go out as soon as row yf is
+  // fused, so about two rows per wave are outstanding at any time -- the kernel is bound by bytes in flight, not by
+  // instruction issue; three inputs only fit one set).
+  constexpr int DEPTH = 1;
+  rf4 raw[DEPTH][NIN][5];
+  auto issue = [&](int yf, auto set_c) __attribute__((always_inline)) {       // (yf inside the image)
+    constexpr int set = decltype(set_c)::value;
+    int srow[NIN];
+#pragma unroll
+    for (int k = 0; k < NIN; ++k) {
+      const int sh = kModes[k] == FUSE_UP2 ? 1 : (kModes[k] == FUSE_UP4 ? 2 : 0);
+      srow[k] = (yf >> sh) * rowstep[k];
+    }
+    // (item-major: the fusion consumes item 0 of every input first, the in-order counter then releases it
+    //  after the first NIN loads instead of after most of the row)
+#pragma unroll
+    for (int it = 0; it < 5; ++it)
+#pragma unroll
+      for (int k = 0; k < NIN; ++k)
+        raw[set][k][it] =
+            __builtin_bit_cast(rf4, __builtin_amdgcn_raw_buffer_load_b128(rs[k], voff[k][it], srow[k], 0));
+  };
+  // fused + activated row yf -> ring slot (yf + 1) % 3 (zeros outside the image: the depthwise padding)
+  auto fuse = [&](int yf, int slot, auto set_c) __attribute__((always_inline)) {
+    constexpr int set = decltype(set_c)::value;
+    unsigned char* dst = smem + slot * kRowB + fdst;
+    if ((unsigned)yf >= (unsigned)a.H) {                             // (uniform) padding row
+#pragma unroll
+      for (int it = 0; it < 5; ++it)
+        if (act_lane && (it < 4 || sub < 2))
+          *reinterpret_cast<rf4*>(dst + it * 4 * kRC * 4) = (rf4){0.f, 0.f, 0.f, 0.f};
+      return;
+    }
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+      rf4 v = bb;
+#pragma unroll
+      for (int k = 0; k < NIN; ++k) v = __builtin_elementwise_fma(raw[set][k][it], ak[k], v);
+      if (ACT == ACT_SILU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] * __builtin_amdgcn_rcpf(1.f + __expf(-v[j]));
+      } else if (ACT == ACT_RELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+      // (items 1..3 are always inside the image: W >= 32, only the strip's first and last columns can be padding)
+      if (it == 0 || it == 4) v *= (rf4){msk[it], msk[it], msk[it], msk[it]};
+      if (act_lane && (it < 4 || sub < 2)) *reinterpret_cast<rf4*>(dst + it * 4 * kRC * 4) = v;
+    }
+  };
+
+  rf4 s1[4], s2[4];
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb) { s1[cb] = (rf4){0.f, 0.f, 0.f, 0.f}; s2[cb] = s1[cb]; }
+
+  // (everything the preamble loaded is waited for HERE: left pending, the compiler puts the wait at the first use
+  //  inside the loop, where the in-order counter then also waits for the rows just requested)
+  __builtin_amdgcn_s_waitcnt(0);
+  int slot = (y_begin + 3) % 3;                    // slot of row yf = y_begin - 1: (yf + 1) % 3
+
+  auto row = [&](int yf, auto set_c) __attribute__((always_inline)) {
+    fuse(yf, slot, set_c);
+    // (this set's registers are free again: request the row DEPTH ahead)
+    if (yf + DEPTH <= y_end && yf + DEPTH < a.H) issue(yf + DEPTH, set_c);
+    const int y = yf - 1;                               // output row whose three ring rows are now complete
+    const int s_top = slot == 0 ? 1 : (slot == 1 ? 2 : 0);          // slot of row y - 1 = (slot + 1) % 3
+    slot = s_top;                                 // (the next fused row replaces row y - 1 after this iteration)
+    if (y < y_begin) return;                                         // (uniform)
+    // ---- depthwise 3x3: lane = (strip of 4 pixels, channel quad) -> operand block ----------------------
+    if (act_lane) {
+      int rs_ = s_top;                                               // ring slot of row y - 1 + dy
+      const unsigned char* src[3];
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        src[dy] = smem + rs_ * kRowB + dsrc;
+        rs_ = rs_ == 2 ? 0 : rs_ + 1;
+      }
+      // (two inputs: all four pixels at once, 18 row reads; three inputs: two pixels at a time, 24 reads but half
+      //  the live registers)
+      constexpr int PXN = kDwReg ? 4 : 2;
+#pragma unroll
+      for (int part = 0; part < 4 / PXN; ++part) {
+        rf4 d[PXN];
+#pragma unroll
+        for (int i = 0; i < PXN; ++i) d[i] = (rf4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          rf4 x[PXN + 2];
+#pragma unroll
+          for (int j = 0; j < PXN + 2; ++j)
+            x[j] = *reinterpret_cast<const rf4*>(src[dy] + (part * PXN + j) * kRC * 4);
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            const rf4 wv = kDwReg ? dwr[kDwReg ? dy * 3 + dx : 0]
+                                  : *reinterpret_cast<const rf4*>(smem + kDwOff + ((dy * 3 + dx) * kRC + c) * 4);
+#pragma unroll
+            for (int i = 0; i < PXN; ++i) d[i] = __builtin_elementwise_fma(x[i + dx], wv, d[i]);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < PXN; ++i) *reinterpret_cast<rf4*>(smem + adst + (part * PXN + i) * kRSA * 4) = d[i];
+      }
+    }
+    // ---- pointwise 1x1: 64 output channels x 16 pixels x 56 channels on the matrix cores -------------------
+    f32x4 acc[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k8 = 0; k8 < kRC / 8; ++k8) {
+      const float2 xc = *reinterpret_cast<const float2*>(smem + ard + k8 * 32);
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[k8][cb][0], xc.x, acc[cb], 0, 0, 0);
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[k8][cb][1], xc.y, acc[cb], 0, 0, 0);
+    }
+    // ---- bias, statistics (in registers across the strip), one 16-byte store per column block ---------------
+    float* yrow = ybase + (size_t)y * a.W * a.cout_p;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      const rf4 b4 = *reinterpret_cast<const rf4*>(smem + kBiasOff + (cb * 16 + kq * 4) * 4);
+      const rf4 v = (rf4){acc[cb][0], acc[cb][1], acc[cb][2], acc[cb][3]} + b4;
+      s1[cb] += v;
+      s2[cb] = __builtin_elementwise_fma(v, v, s2[cb]);
+      if (cb * 16 + kq * 4 < a.cout_p) *reinterpret_cast<rf4*>(yrow + cb * 16) = v;
+    }
+  };
+  using C0 = std::integral_constant<int, 0>;
+  using C1 = std::integral_constant<int, DEPTH - 1>;
+  if (y_begin - 1 >= 0) issue(y_begin - 1, C0{});
+  if (DEPTH == 2) issue(y_begin, C1{});                              // (y_begin < H always)
+  for (int yf = y_begin - 1; yf <= y_end; yf += DEPTH) {
+    row(yf, C0{});
+    if (DEPTH == 2 && yf + 1 <= y_end) row(yf + 1, C1{});
+  }
+  if (a.stats) {
+    // sum over the 16 pixel lanes of a DPP row: xor 1, xor 2 (quad permutes), half-row mirror, row mirror
+    auto row_sum = [](float x) __attribute__((always_inline)) {
+      x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true));
+      x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xF, 0xF, true));
+      x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x141, 0xF, 0xF, true));
+      x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x140, 0xF, 0xF, true));
+      return x;
+    };
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float t1 = row_sum(s1[cb][i]), t2 = row_sum(s2[cb][i]);
+        const int ch = cb * 16 + kq * 4 + i;
+        if (mrow == 0 && ch < a.cout_p) stat_add(a.stats + ((size_t)n * a.cout_p + ch) * kStatW, t1, t2);
+      }
+  }
+}
+
+// Which nodes take the row-streaming form: the 56-channel pyramid, 64 output channels' worth of column
+// blocks, no max-pooled input, level at least 32 pixels wide and a multiple of 16 (JH_NODE_ROWS=0: never).
+bool bifpn_rows_eligible(const NodeArgs& a) {
+  if (JH_ENV_KNOB("JH_NODE_ROWS") == 0) return false;
+  if (a.Cp != kRC || a.cout_p16 != 64 || a.W % 16 != 0 || a.W < 32 || a.H < 16) return false;
+  if (a.mode[0] != FUSE_SAME) return false;
+  // (one wave per workgroup walking >= 10 rows: below ~2048 strips the chip is not filled and the tile form wins)
+  const int min_wg = JH_ENV_KNOB("JH_NODE_ROWS_MINWG") > 0 ? JH_ENV_KNOB("JH_NODE_ROWS_MINWG") : 2048;
+  if ((a.W / 16) * ((a.H + 7) / 8) * a.N < min_wg) return false;
+  if (a.n_in == 2) return a.mode[1] == FUSE_UP2;
+  return a.n_in == 3 && a.mode[1] == FUSE_UP2 && a.mode[2] == FUSE_UP4;
+}
+
+int launch_bifpn_rows(const NodeArgs& a, hipStream_t s) {
+  const int strips = a.W / 16;
+  int seg_rows = JH_ENV_KNOB("JH_NODE_SEG") > 0 ? JH_ENV_KNOB("JH_NODE_SEG") : 32;
+  if (seg_rows > a.H) seg_rows = a.H;
+  while (seg_rows > 8 && strips * ((a.H + seg_rows - 1) / seg_rows) * a.N < 4096) seg_rows /= 2;
+  const int segs = (a.H + seg_rows - 1) / seg_rows;
+  const size_t lds = (size_t)(3 * kRPX * kRC + kAFloats + 9 * kRC + 64) * sizeof(float);
+  const dim3 grid(strips * segs, a.N);
+#define JH_ROWS(NIN, M1, M2, ACT) \
+  hipLaunchKernelGGL((bifpn_rows_kernel<NIN, M1, M2, ACT>), grid, dim3(64), lds, s, a, seg_rows, strips)
+  if (a.n_in == 2) {
+    if (a.act == ACT_SILU) JH_ROWS(2, FUSE_UP2, 0, ACT_SILU);
+    else if (a.act == ACT_NONE) JH_ROWS(2, FUSE_UP2, 0, ACT_NONE);
+    else JH_REQUIRE(false, "row-streaming node: activation");
+  } else {
+    if (a.act == ACT_SILU) JH_ROWS(3, FUSE_UP2, FUSE_UP4, ACT_SILU);
+    else if (a.act == ACT_NONE) JH_ROWS(3, FUSE_UP2, FUSE_UP4, ACT_NONE);
+    else JH_REQUIRE(false, "row-streaming node: activation");
+  }
+#undef JH_ROWS
+  JH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace jh

@@ -98,11 +98,7 @@ def test_predictor3d_time_batch():
             assert torch.equal(pts[t], p[0]) and torch.equal(conf[t], q[0])
 
 
-def test_time_batch_at_bench_scale():
-    """16 frame sets of configs[2] in one call (192 images per 2D network launch: several workgroups
-    resident per CU, thousands per launch -- the regime bench.py runs in) give, frame by frame, the bits of
-    the single-frame call.  Guards against occupancy-dependent faults that the small cases cannot show
-    (a store-data hazard of a reverted epilogue only appeared with two workgroups per CU)."""
+def _time_batch_at_bench_scale(strict):
     from jarvis_hybridnet_amd._predictor import NativePredictor
     from jarvis_hybridnet_amd import synthetic as S
     c = cases.PREDICTOR_CASES["cfg3"]
@@ -123,7 +119,37 @@ def test_time_batch_at_bench_scale():
         out = [t.clone() for t in pT.forward(frames)]
         torch.cuda.synchronize()
         for t in range(T):
-            assert torch.equal(out[0][t], ref[0][0]) and torch.equal(out[1][t], ref[1][0]), t
+            # every frame of the batch: the bits of frame 0 (same kernels, other workgroups / CUs / occupancy)
+            assert torch.equal(out[0][t], out[0][0]) and torch.equal(out[1][t], out[1][0]), t
+            if strict:
+                assert torch.equal(out[0][t], ref[0][0]) and torch.equal(out[1][t], ref[1][0]), t
+        # against the single-frame call: at this size the P3 / P4 BiFPN nodes run in their row-streaming form
+        # (bifpn_rows.hip), whose per-strip float partial sums of the InstanceNorm statistics group the pixels
+        # differently from the tile form the 12-image call uses -- same values to float rounding, not the same bits
+        assert float((out[0][0] - ref[0][0]).abs().max()) <= 1e-4
+        assert float((out[1][0] - ref[1][0]).abs().max()) <= 1e-5
+
+
+def test_time_batch_at_bench_scale():
+    """16 frame sets of configs[2] in one call (192 images per 2D network launch: several workgroups
+    resident per CU, thousands per launch -- the regime bench.py runs in) give, for every frame, the same bits,
+    and the single-frame call's result to 1e-4 mm.  Guards against occupancy-dependent faults that the small
+    cases cannot show (a store-data hazard of a reverted epilogue only appeared with two workgroups per CU)."""
+    _time_batch_at_bench_scale(strict=False)
+
+
+def test_time_batch_at_bench_scale_tile_nodes_bit_equal():
+    """The same with the row-streaming nodes switched off (JH_NODE_ROWS=0, read once per process: a child
+    process): every kernel is then the one the single-frame call runs, and the batch must reproduce its bits."""
+    import subprocess
+    import sys
+    env = dict(os.environ, JH_NODE_ROWS="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("from tests import test_hip_predictor as t; t._time_batch_at_bench_scale(strict=True); "
+            "print('strict ok')")
+    res = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True,
+                         timeout=600)
+    assert res.returncode == 0 and "strict ok" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
 
 
 def test_sharded_stages_emulated_two_ranks():

@@ -23,7 +23,7 @@ SPECS = {
     "conv3d_k3s1wino_46x46@32": ("%conv3d_wino_pw_kernel%", "most_dispatches"),
     "conv3d_k3s1wino_92x92@16": ("%conv3d_wino_pw_kernel%", "fewest_dispatches"),
     "reproject_gather": ("%repro_cube_kernel%", "largest_grid"),
-    "bifpn_node_56x56@64": ("%bifpn_node_kernel%", "largest_grid"),
+    "bifpn_node_56x56@64": ("%bifpn_rows_kernel<2,%", "largest_grid"),
     "preprocess_resize": ("%preprocess_resize%", "largest_grid"),
 }
 
