@@ -338,12 +338,16 @@ int jh_predictor_create(const jh_params* center_params, const jh_params* hybrid_
   JH_REQUIRE(cfg->cam_lo >= 0 && cfg->cam_n >= 1 && cfg->cam_lo + cfg->cam_n <= pr->C, "camera range");
   JH_REQUIRE(pr->G % 4 == 0, "ROI_CUBE_SIZE / GRID_SPACING must be a multiple of 4");
   const int N = pr->T * pr->Cloc;
+  // (form of the BiFPN nodes: by the time batch alone, see EffTrackPlan::node_rows)
+  const int node_rows = pr->T >= 8 ? 1 : 0;
   if (center_params) {
     pr->center.reset(new EffTrackPlan());
+    pr->center->node_rows = node_rows;
     if (pr->center->build(center_params->map, "", cfg->center_model, 1, N, cfg->center_size,
                           cfg->center_size)) return 1;
   }
   pr->kp.reset(new EffTrackPlan());
+  pr->kp->node_rows = node_rows;
   if (pr->kp->build(hybrid_params->map, "effTrack.", cfg->kp_model, pr->J, N, pr->B, pr->B)) return 1;
   pr->v2v.reset(new V2VPlan());
   if (pr->v2v->build(hybrid_params->map, "v2vNet.", pr->J, pr->T3, pr->G)) return 1;

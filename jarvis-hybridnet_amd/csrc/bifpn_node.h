@@ -19,6 +19,7 @@ struct NodeArgs {
   int N, H, W, Cp, cout_p, cout_p16, cf;
   int blds = 0;            // pointwise weights staged in LDS behind the operand tile
   int alias = 0;           // operand tile written over the halo tile (single channel chunk)
+  int rows = -1;           // row-streaming form (bifpn_rows.hip): 1 wherever the shape allows, 0 never, -1 by launch size
   int abl = 0;             // ablation bits for timing experiments (0 in production)   // cf = channels per halo chunk (multiple of 4)
 };
 

@@ -283,21 +283,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // Which nodes take the row-streaming form: the 56-channel pyramid, 64 output channels' worth of column
 // blocks, no max-pooled input, level at least 32 pixels wide and a multiple of 16 (JH_NODE_ROWS=0: never).
 bool bifpn_rows_eligible(const NodeArgs& a) {
-  if (JH_ENV_KNOB("JH_NODE_ROWS") == 0) return false;
+  if (JH_ENV_KNOB("JH_NODE_ROWS") == 0 || a.rows == 0) return false;
   if (a.Cp != kRC || a.cout_p16 != 64 || a.W % 16 != 0 || a.W < 32 || a.H < 16) return false;
   if (a.mode[0] != FUSE_SAME) return false;
-  // (one wave per workgroup walking >= 10 rows: below ~2048 strips the chip is not filled and the tile form wins)
-  const int min_wg = JH_ENV_KNOB("JH_NODE_ROWS_MINWG") > 0 ? JH_ENV_KNOB("JH_NODE_ROWS_MINWG") : 2048;
-  if ((a.W / 16) * ((a.H + 7) / 8) * a.N < min_wg) return false;
+  if (a.rows < 0) {
+    // (one wave per workgroup walking >= 10 rows: below ~2048 strips the chip is not filled and the tile form wins)
+    const int min_wg = JH_ENV_KNOB("JH_NODE_ROWS_MINWG") > 0 ? JH_ENV_KNOB("JH_NODE_ROWS_MINWG") : 2048;
+    if ((a.W / 16) * ((a.H + 7) / 8) * a.N < min_wg) return false;
+  }
   if (a.n_in == 2) return a.mode[1] == FUSE_UP2;
   return a.n_in == 3 && a.mode[1] == FUSE_UP2 && a.mode[2] == FUSE_UP4;
 }
 
 int launch_bifpn_rows(const NodeArgs& a, hipStream_t s) {
   const int strips = a.W / 16;
-  int seg_rows = JH_ENV_KNOB("JH_NODE_SEG") > 0 ? JH_ENV_KNOB("JH_NODE_SEG") : 32;
+  // Rows per workgroup: a function of the image size ONLY -- the float partial sums of the statistics are taken per
+  // strip segment, so the segmentation must not depend on how many images a launch carries (bit-equal results
+  // for any number of cameras per rank).  16 rows: 1.125 x fusion work; 8 for the smaller levels (more workgroups).
+  int seg_rows = JH_ENV_KNOB("JH_NODE_SEG") > 0 ? JH_ENV_KNOB("JH_NODE_SEG") : (a.H >= 64 ? 16 : 8);
   if (seg_rows > a.H) seg_rows = a.H;
-  while (seg_rows > 8 && strips * ((a.H + seg_rows - 1) / seg_rows) * a.N < 4096) seg_rows /= 2;
   const int segs = (a.H + seg_rows - 1) / seg_rows;
   const size_t lds = (size_t)(3 * kRPX * kRC + kAFloats + 9 * kRC + 64) * sizeof(float);
   const dim3 grid(strips * segs, a.N);

@@ -101,6 +101,11 @@ class EffTrackPlan : public Plan {
   // never read.  mode 0 (default): the stem reads `input`.
   bool stem_fusable = false;
   StemSource stem_src;
+  // Which form the high-resolution BiFPN nodes take (NodeArgs::rows), set before build().  A predictor sets it
+  // from its time batch ALONE (not from the number of cameras it owns), so that a camera-sharded rank and the
+  // single-GPU run of the same time batch launch the same kernels and stay bit-equal; -1: by the
+  // number of workgroups of the launch (stand-alone operator).
+  int node_rows = -1;
   Act input;     // [N][H][W][8]   normalised image, channel-last
   Act heat;      // [N][H/2][W/2][Jp]  res2 (ConvTranspose output)
   Act res1;      // [N][H/4][W/4][Jp]  final_conv1 output (only with want_res1)

@@ -392,6 +392,7 @@ int EffTrackPlan::node(const ParamMap& pm, const std::string& cp, int n_in, cons
   a.dw = dwd; a.pw = cw.w; a.bias = cw.bias; a.y = out->a.p;
   a.N = like.N; a.H = like.H; a.W = like.W; a.Cp = like.Cp;
   a.cout_p = out->a.Cp; a.cout_p16 = cw.cout_p16;
+  a.rows = node_rows;
   const double px = (double)like.N * like.pixels();
   char nm[64];
   snprintf(nm, sizeof nm, "bifpn_node_%dx%d@%d", cin, cout, like.W);

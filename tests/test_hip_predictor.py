@@ -152,8 +152,11 @@ def test_time_batch_at_bench_scale_tile_nodes_bit_equal():
     assert res.returncode == 0 and "strict ok" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
 
 
-def test_sharded_stages_emulated_two_ranks():
-    """The camera-sharded stage API on ONE GPU: two NativePredictors own half of
+@pytest.mark.parametrize("T", [2, 8])
+def test_sharded_stages_emulated_two_ranks(T):
+    """(T = 8: the time batch from which the high-resolution BiFPN nodes take their row-streaming form -- chosen by
+    the time batch alone, so a rank owning half of the cameras still launches the kernels of the full run.)
+    The camera-sharded stage API on ONE GPU: two NativePredictors own half of
     the cameras each, the two exchanges of distributed.py are done by hand
     (concatenation = what the collectives deliver).  Result must equal the
     single-predictor forward bit-for-bit (sharding only moves data; InstanceNorm
@@ -163,8 +166,9 @@ def test_sharded_stages_emulated_two_ranks():
     c = cases.PREDICTOR_CASES["cfg2"]
     inp = cases.predictor_inputs("cfg2")
     calib = (inp["cam"], inp["intr"], inp["dist"])
-    T, C, J, world = 2, c["C"], c["J"], 2
-    frames = cuda(torch.stack([inp["imgs"], S.blob_frames(calib, c["W"], c["H"], J, 60)[0]]))
+    C, J, world = c["C"], c["J"], 2
+    frames = cuda(torch.stack([inp["imgs"]] + [S.blob_frames(calib, c["W"], c["H"], J, 60 + i)[0]
+                                               for i in range(T - 1)]))
     common = dict(num_cameras=C, num_joints=J, center_size=c["center_size"], bbox=c["bbox"],
                   roi_cube_size=c["roi"], grid_spacing=c["spacing"], img_h=c["H"], img_w=c["W"],
                   mean=S.MEAN, std=S.STD, time_batch=T)
