@@ -188,17 +188,22 @@ def test_conv3d_winograd_persistent(cin, cout, N, G, in_norm, monkeypatch):
 
 
 
-NODE_CASES = [  # (C, Cout, H, W, modes, act): the node shapes of the small / medium pyramids
-    (56, 56, 64, 64, (0, 1), 2),            # top-down P3: same level + nearest x2 of P4
-    (56, 56, 32, 32, (0, 0, 3), 2),         # bottom-up P4: two same-level inputs + 2x2 max-pool of P3
-    (56, 56, 8, 8, (0, 3), 2),              # P7 of the bottom-up pass
-    (56, 64, 64, 64, (0, 1, 2), 0),         # head: P3 + x2 P4 + x4 P5 -> first_conv (no activation)
-    (88, 88, 32, 32, (0, 0, 3), 2),         # medium model: wider pyramid (chunked halo path)
+NODE_CASES = [  # (C, Cout, H, W, modes, act, n): the node shapes of the small / medium pyramids
+    (56, 56, 64, 64, (0, 1), 2, 3),         # top-down P3: same level + nearest x2 of P4
+    (56, 56, 32, 32, (0, 0, 3), 2, 3),      # bottom-up P4: two same-level inputs + 2x2 max-pool of P3
+    (56, 56, 8, 8, (0, 3), 2, 3),           # P7 of the bottom-up pass
+    (56, 64, 64, 64, (0, 1, 2), 0, 3),      # head: P3 + x2 P4 + x4 P5 -> first_conv (no activation)
+    (88, 88, 32, 32, (0, 0, 3), 2, 3),      # medium model: wider pyramid (chunked halo path)
+    # >= 2048 strips per launch: the stand-alone operator takes the row-streaming form (csrc/bifpn_rows.hip)
+    (56, 56, 64, 64, (0, 1), 2, 64),        # P3 top-down, 16-row segments
+    (56, 64, 64, 64, (0, 1, 2), 0, 64),     # head (three inputs, no activation, 64 output channels)
+    (56, 56, 32, 32, (0, 1), 2, 256),       # P4 top-down, 8-row segments
+    (56, 56, 48, 32, (0, 1), 2, 192),       # height that is not a power of two
 ]
 
 
-@pytest.mark.parametrize("C,Cout,H,W,modes,act", NODE_CASES)
-def test_bifpn_node(C, Cout, H, W, modes, act):
+@pytest.mark.parametrize("C,Cout,H,W,modes,act,n", NODE_CASES)
+def test_bifpn_node(C, Cout, H, W, modes, act, n):
     """One fused BiFPN node (csrc/bifpn_node.hip) against torch: InstanceNorm of every raw input
     applied on load, fast-normalised weighted fusion with nearest up-sampling / 2x2 max-pooling
     of the neighbour levels, SiLU, depthwise 3x3, pointwise 1x1 + bias -- the fusion expressions of
@@ -207,7 +212,6 @@ def test_bifpn_node(C, Cout, H, W, modes, act):
     import ctypes
     from jarvis_hybridnet_amd import _native as N
     g = torch.Generator().manual_seed(C + H + len(modes))
-    n = 3
     shape = {0: (H, W), 1: (H // 2, W // 2), 2: (H // 4, W // 4), 3: (H * 2, W * 2)}
     xs = [torch.randn(n, C, *shape[m], generator=g) * (1.0 + i) + 0.3 * i for i, m in enumerate(modes)]
     wts = torch.rand(len(modes), generator=g) + 0.2
@@ -237,5 +241,5 @@ def test_bifpn_node(C, Cout, H, W, modes, act):
                                      bias.contiguous().data_ptr(), y.data_ptr(), N.stream()))
     torch.cuda.synchronize()
     e = rel_err(y, ref)
-    report("bifpn_node", c=C, cout=Cout, h=H, modes=str(modes), rel=e)
+    report("bifpn_node", c=C, cout=Cout, h=H, modes=str(modes), n=n, rel=e)
     assert e < 2e-5
