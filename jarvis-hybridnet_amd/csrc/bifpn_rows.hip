@@ -20,7 +20,7 @@
 // The kernel is bound by instruction issue, not by memory (three inputs run as fast as two): per row and wave
 // 56 MFMAs x 32 cycles + ~100 packed FMAs + 40 exp / rcp + ~40 LDS and 14 memory instructions ~ 5 000 cycles,
 // which is what it measures (a SIMD issues one stream, times add).  P3 node of the bench
-// (384 images 64 x 64): 273.6 -> 216 us, head 304 -> 241 us.
+// (384 images 64 x 64): 273.6 -> 204.5 us, head 304 -> 219.5 us.
 #include <type_traits>
 
 #include "conv_mfma.h"
@@ -33,6 +33,7 @@ constexpr int kRC = 56, kRQ = kRC / 4, kRPX = 18, kRSA = kRC + 4;       // chann
 constexpr int kAFloats = 16 * kRSA;
 typedef float rf2 __attribute__((ext_vector_type(2)));
 typedef float rf4 __attribute__((ext_vector_type(4)));
+typedef unsigned ru4 __attribute__((ext_vector_type(4)));
 }  // namespace
 
 template <int NIN, int M1, int M2, int ACT>
@@ -124,15 +125,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   const int dsrc = (sub * 4 * kRC + c) * 4;                     // + ring slot + tap (imm)
   const int adst = kAtOff + (sub * 4 * kRSA + c) * 4;           // + pixel (imm)
   const int ard = kAtOff + (mrow * kRSA) * 4 + kq * 8;          // + channel step (imm)
-  float* const ybase = a.y + ((size_t)n * a.H * a.W + ox0 + mrow) * a.cout_p + kq * 4;
+  // Output through a buffer descriptor of image n: lanes whose four channels lie past cout_p (the padding of the
+  // last column block) store with bit 31 set in the offset -- dropped by the range check -- instead of under a
+  // branch: a store the compiler cannot count makes every later wait for loads a wait for ALL memory operations.
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+      a.y + (size_t)n * a.H * a.W * a.cout_p, 0, (int)((size_t)a.H * a.W * a.cout_p * 4), 0x00020000);
+  int yoff[4];
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb)
+    yoff[cb] = cb * 16 + kq * 4 < a.cout_p ? ((ox0 + mrow) * a.cout_p + cb * 16 + kq * 4) * 4 : (int)0x80000000;
 
   // Raw rows in flight: DEPTH register sets (2 for two inputs: the loads of row yf + 2 go out as soon as row yf is
   // fused, so about two rows per wave are outstanding at any time -- the kernel is bound by bytes in flight, not by
   // instruction issue; three inputs only fit one set).
   constexpr int DEPTH = 1;
   rf4 raw[DEPTH][NIN][5];
-  auto issue = [&](int yf, auto set_c) __attribute__((always_inline)) {       // (yf inside the image)
+  // An up-sampled input changes its source row only every 2nd output row: when the requested row is ODD its
+  // registers are simply kept (5 load instructions less).  `all_c` is a compile-time flag -- the row loop is
+  // unrolled by two -- because a load under a run-time branch makes the compiler's in-order wait counts
+  // pessimistic (the fusion then also waits for the previous row's stores: 216 -> 326 us).
+  auto issue = [&](int yf, auto set_c, auto all_c) __attribute__((always_inline)) {       // (yf inside the image)
     constexpr int set = decltype(set_c)::value;
+    constexpr bool all = decltype(all_c)::value;
     int srow[NIN];
 #pragma unroll
     for (int k = 0; k < NIN; ++k) {
@@ -145,8 +159,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     for (int it = 0; it < 5; ++it)
 #pragma unroll
       for (int k = 0; k < NIN; ++k)
-        raw[set][k][it] =
-            __builtin_bit_cast(rf4, __builtin_amdgcn_raw_buffer_load_b128(rs[k], voff[k][it], srow[k], 0));
+        if (all || kModes[k] == FUSE_SAME)
+          raw[set][k][it] =
+              __builtin_bit_cast(rf4, __builtin_amdgcn_raw_buffer_load_b128(rs[k], voff[k][it], srow[k], 0));
   };
   // fused + activated row yf -> ring slot (yf + 1) % 3 (zeros outside the image: the depthwise padding)
   auto fuse = [&](int yf, int slot, auto set_c) __attribute__((always_inline)) {
@@ -186,14 +201,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   __builtin_amdgcn_s_waitcnt(0);
   int slot = (y_begin + 3) % 3;                    // slot of row yf = y_begin - 1: (yf + 1) % 3
 
-  auto row = [&](int yf, auto set_c) __attribute__((always_inline)) {
+  auto row = [&](int yf, auto set_c, auto next_all_c, auto out_c) __attribute__((always_inline)) {
     fuse(yf, slot, set_c);
     // (this set's registers are free again: request the row DEPTH ahead)
-    if (yf + DEPTH <= y_end && yf + DEPTH < a.H) issue(yf + DEPTH, set_c);
+    if (yf + DEPTH <= y_end && yf + DEPTH < a.H) issue(yf + DEPTH, set_c, next_all_c);
     const int y = yf - 1;                               // output row whose three ring rows are now complete
     const int s_top = slot == 0 ? 1 : (slot == 1 ? 2 : 0);          // slot of row y - 1 = (slot + 1) % 3
     slot = s_top;                                 // (the next fused row replaces row y - 1 after this iteration)
-    if (y < y_begin) return;                                         // (uniform)
+    if (!decltype(out_c)::value) return;             // (the two rows above the segment's first output row)
     // ---- depthwise 3x3: lane = (strip of 4 pixels, channel quad) -> operand block ----------------------
     if (act_lane) {
       int rs_ = s_top;                                               // ring slot of row y - 1 + dy
@@ -242,23 +257,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[k8][cb][1], xc.y, acc[cb], 0, 0, 0);
     }
     // ---- bias, statistics (in registers across the strip), one 16-byte store per column block ---------------
-    float* yrow = ybase + (size_t)y * a.W * a.cout_p;
+    const int yrow = y * a.W * a.cout_p * 4;
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
       const rf4 b4 = *reinterpret_cast<const rf4*>(smem + kBiasOff + (cb * 16 + kq * 4) * 4);
       const rf4 v = (rf4){acc[cb][0], acc[cb][1], acc[cb][2], acc[cb][3]} + b4;
       s1[cb] += v;
       s2[cb] = __builtin_elementwise_fma(v, v, s2[cb]);
-      if (cb * 16 + kq * 4 < a.cout_p) *reinterpret_cast<rf4*>(yrow + cb * 16) = v;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ru4, v), ry, yoff[cb] + yrow, 0, 0);
     }
   };
   using C0 = std::integral_constant<int, 0>;
   using C1 = std::integral_constant<int, DEPTH - 1>;
-  if (y_begin - 1 >= 0) issue(y_begin - 1, C0{});
-  if (DEPTH == 2) issue(y_begin, C1{});                              // (y_begin < H always)
-  for (int yf = y_begin - 1; yf <= y_end; yf += DEPTH) {
-    row(yf, C0{});
-    if (DEPTH == 2 && yf + 1 <= y_end) row(yf + 1, C1{});
+  // (segments start on even rows -- launch_bifpn_rows -- so row y_begin - 1 is odd and the rows requested from the
+  //  first half of the unrolled body are even: all inputs; from the second half odd: same-level inputs only)
+  if (y_begin - 1 >= 0) issue(y_begin - 1, C0{}, std::true_type{});
+  if (DEPTH == 2) issue(y_begin, C1{}, std::true_type{});                              // (y_begin < H always)
+  // The first two fused rows produce no output yet: peeled, so that the loop body has no path without stores --
+  // with one, the compiler's in-order wait counts for the loads must assume the stores were never issued and
+  // every wait for a load becomes a wait for (nearly) all of them.
+  row(y_begin - 1, C0{}, std::true_type{}, std::false_type{});
+  row(y_begin, C1{}, std::integral_constant<bool, DEPTH == 2>{}, std::false_type{});
+  for (int yf = y_begin + 1; yf <= y_end; yf += 2) {
+    row(yf, C0{}, std::true_type{}, std::true_type{});
+    if (yf + 1 <= y_end) row(yf + 1, C1{}, std::integral_constant<bool, DEPTH == 2>{}, std::true_type{});
   }
   if (a.stats) {
     // sum over the 16 pixel lanes of a DPP row: xor 1, xor 2 (quad permutes), half-row mirror, row mirror
@@ -301,6 +323,7 @@ int launch_bifpn_rows(const NodeArgs& a, hipStream_t s) {
   // strip segment, so the segmentation must not depend on how many images a launch carries (bit-equal results
   // for any number of cameras per rank).  16 rows: 1.125 x fusion work; 8 for the smaller levels (more workgroups).
   int seg_rows = JH_ENV_KNOB("JH_NODE_SEG") > 0 ? JH_ENV_KNOB("JH_NODE_SEG") : (a.H >= 64 ? 16 : 8);
+  seg_rows = (seg_rows + 1) & ~1;                // (even: the kernel's row loop is unrolled by two on row parity)
   if (seg_rows > a.H) seg_rows = a.H;
   const int segs = (a.H + seg_rows - 1) / seg_rows;
   const size_t lds = (size_t)(3 * kRPX * kRC + kAFloats + 9 * kRC + 64) * sizeof(float);
