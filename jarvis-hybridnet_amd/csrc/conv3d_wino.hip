@@ -383,15 +383,23 @@ int launch_conv3d_wino(const ConvWeights& w, const Act& x, const Act& y, double*
   if (in && in->stats) { a.in_stats = in->stats; a.in_inv = in->inv; a.in_act = in->act; }
   a.N = x.N; a.D = x.D; a.H = x.H; a.W = x.W; a.cin_p = x.Cp; a.cout_p = y.Cp; a.cout_p16 = w.cout_p16;
   const int nb = w.cout_p16 / 16;
-  const int nr = (nb % 3 == 0) ? 3 : ((nb % 2 == 0) ? 2 : (nb == 1 ? 1 : 3));
+  const int nr_full = (nb % 3 == 0) ? 3 : ((nb % 2 == 0) ? 2 : (nb == 1 ? 1 : 3));
   // (2 z-slices per workgroup measure the same as 4: the second resident workgroup only pays for
   // the doubled per-workgroup prologue / epilogue; kept as an experiment knob)
   const int tz = variant == 1 ? 2 : 4;
   if (variant == 4) {
-    const int rc = launch_conv3d_wino_pw(a, nr, s);
+    const int rc = launch_conv3d_wino_pw(a, nr_full, s);
     if (rc >= 0) return rc;                 // -1: too few tiles / one channel pass -> one-role kernel
   }
   const int blocks = ((x.D + tz - 1) / tz) * ((x.H + kWTY - 1) / kWTY) * ((x.W + kWTX - 1) / kWTX);
+  // Single-frame-set launches have fewer tiles than the chip has CUs (32 / 128 at 16^3 / 32^3): fewer column
+  // blocks per workgroup then, i.e. more workgroups that each repeat the input transform but run a half / a
+  // third of the MFMAs.  (nr only partitions the output channels: the fp32 partial sums of the statistics --
+  // per channel over a tile's voxels -- and every output value are the same bits for any nr.)
+  int nr_l = nr_full;
+  if (JH_ENV_KNOB("JH_WINO_NR_SPLIT") != 0)
+    while (nr_l > 1 && (long)blocks * ((nb + nr_l - 1) / nr_l) * x.N <= 128) --nr_l;
+  const int nr = nr_l;
   dim3 grid(blocks, (nb + nr - 1) / nr, x.N);
   const size_t xbytes = (size_t)4 * 2 * tz * nr * 4 * 64 * sizeof(float);
   size_t lds = (size_t)((tz + 2) * kWPY * kWPX * 8 + (tz + 2) * 16 * 16 * kWSV) * sizeof(float);

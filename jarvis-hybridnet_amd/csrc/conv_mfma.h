@@ -730,6 +730,13 @@ int launch_conv_geom(const ConvArgs& a, int nr, size_t lds_budget, hipStream_t s
   b.kc = kc8 * 8;
   const int tiles = ((b.Dout + TZ - 1) / TZ) * ((b.Hout + TY - 1) / TY) * ((b.Wout + TX - 1) / TX);
   const int nb = b.cout_p16 / 16;
+  // Launches that cannot fill the chip (the single-frame-set call: 24 tiles at 16 x 16 x 12 images): fewer column
+  // blocks per workgroup = more workgroups, each staging the same operand but running a fraction of the MFMAs.
+  // nr only partitions the output channels, so outputs and the per-channel fp32 partials of the fused statistics
+  // are the same bits for any nr (test_time_batch_at_bench_scale_tile_nodes_bit_equal compares a 12-image call,
+  // which takes this path, with a 192-image one, which does not).
+  if (JH_ENV_KNOB("JH_CONV_NR_SPLIT") != 0)
+    while (nr > 1 && (long)tiles * ((nb + nr - 1) / nr) * b.N * b.nphase <= 128) --nr;
   dim3 grid(tiles, (nb + nr - 1) / nr, b.N * b.nphase);
 #define JH_CONV_CASE(NRV, KV) \
   if (nr == NRV && kc8 == KV) return launch_conv_inst<ND, K, STRIDE, TZ, TY, TX, NRV, KV>(b, grid, s);
