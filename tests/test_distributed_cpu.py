@@ -102,16 +102,24 @@ class OracleStages:
                 pts[i], conf[i], valid[i] = p[0], cf[0], self.state[("valid", t)]
 
 
-def _worker(rank, world, port, exchange, q, T=T, three_d="sharded"):
+def _worker(rank, world, port, exchange, q, T=T, three_d="sharded", gs=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    calib, sd_c, sd_h, frames = make_inputs(T)
-    lo, n = camera_range(C, rank, world)
+    calib, sd_c, sd_h, frames = make_inputs(T if gs is None else T * (world // gs))
+    group, grank, gworld, gidx = None, rank, world, 0
+    if gs is not None:
+        # the 8-GPU layout of bench.py in small: world // gs groups of gs ranks, each group shards the
+        # cameras of ITS time batch (every rank creates every group, as torch.distributed requires)
+        groups = [dist.new_group(list(range(g * gs, (g + 1) * gs))) for g in range(world // gs)]
+        gidx, grank, gworld = rank // gs, rank % gs, gs
+        group = groups[gidx]
+        frames = frames[gidx * T:(gidx + 1) * T]
+    lo, n = camera_range(C, grank, gworld)
     st = OracleStages(calib, sd_c, sd_h, lo, n)
     sh = ShardedPredictor(st, num_cameras=C, num_joints=J, time_batch=T,
-                          heat_shape=(BBOX // 2, BBOX // 2, JP), rank=rank, world=world,
-                          device="cpu", exchange=exchange, three_d=three_d)
+                          heat_shape=(BBOX // 2, BBOX // 2, JP), rank=grank, world=gworld,
+                          device="cpu", exchange=exchange, three_d=three_d, group=group)
     mine = frames[:, lo:lo + n].contiguous()
     pts, conf, valid = sh.step(mine)
     # pipelined form: batch B (frames in reverse order) is submitted while batch A is in
@@ -125,8 +133,9 @@ def _worker(rank, world, port, exchange, q, T=T, three_d="sharded"):
         assert torch.equal(x, y), "pipelined batch A differs from step()"
     for x, y in zip(b, (pts.flip(0), conf.flip(0), valid.flip(0))):
         assert torch.equal(x, y), "pipelined batch B differs from step() on the same frames"
-    if rank == 0:
-        q.put((pts.clone(), conf.clone(), valid.clone()))
+    if grank == 0:
+        q.put((pts.clone(), conf.clone(), valid.clone()) if gs is None else
+              (gidx, pts.clone(), conf.clone(), valid.clone()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -164,6 +173,37 @@ def test_camera_sharded_equals_single_process(exchange, world, three_d):
             # treat images as independent instances, see test_predictor3d_time_batch.)
             assert (pts[t] - rp[0]).abs().max().item() < 1e-3
             assert (conf[t] - rc[0]).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("three_d", ["sharded", "rank0"])
+def test_two_groups_of_two_ranks(three_d):
+    """The layout `bench.py --gpus 8` uses for 12 cameras (2 groups of 4 GPUs), in small: world 4 = 2 groups of
+    2 ranks, each group camera-shards its own time batch over a sub-group communicator.  three_d='rank0'
+    broadcasts from the GROUP's first rank (global rank 2 in the second group)."""
+    world, gs = 4, 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, "alltoall", q, T, three_d, gs))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict((g, (a, b, c)) for g, a, b, c in (q.get(timeout=240) for _ in range(world // gs)))
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    calib, sd_c, sd_h, frames = make_inputs(T * (world // gs))
+    for g in range(world // gs):
+        pts, conf, valid = got[g]
+        for t in range(T):
+            with torch.no_grad():
+                rp, rc = O.predictor3d_forward(sd_c, sd_h, frames[g * T + t], *calib, **KW)
+            assert int(valid[t]) == (rp is not None)
+            if rp is not None:
+                assert (pts[t] - rp[0]).abs().max().item() < 1e-3
+                assert (conf[t] - rc[0]).abs().max().item() < 1e-5
 
 
 def test_plan_groups():
