@@ -1,6 +1,8 @@
 """Soak check at the bench's scale: a time batch of 32 frame sets of configs[2] (384 images per 2D launch)
-run repeatedly on three concurrent streams; every run of every stream must reproduce the first bit for bit,
-and every frame of the batch must equal the single-frame result."""
+run repeatedly on three concurrent streams; every frame of every run of every stream must reproduce the first
+frame of the first run bit for bit, and lie within 1e-4 mm of the single-frame call's result (bit-equal to it with
+JH_NODE_ROWS=0: a time batch of >= 8 frames takes the row-streaming BiFPN nodes, the single-frame call the tile
+form)."""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import torch
@@ -29,6 +31,8 @@ for s in streams:
         preds.append(p)
 torch.cuda.synchronize()
 bad = 0
+first = None
+strict = os.environ.get("JH_NODE_ROWS") == "0" or T < 8
 for r in range(REPS):
     outs = []
     for s, p in zip(streams, preds):
@@ -36,8 +40,14 @@ for r in range(REPS):
             outs.append([t.clone() for t in p.forward(frames)])
     torch.cuda.synchronize()
     for o in outs:
+        if first is None:
+            first = (o[0][0].clone(), o[1][0].clone())
+            d = float((first[0] - ref[0][0]).abs().max())
+            print("soak: batch vs single-frame call: %.3g mm%s" % (d, " (bit-equal required)" if strict else ""))
+            if d > 1e-4 or (strict and not (torch.equal(first[0], ref[0][0]) and torch.equal(first[1], ref[1][0]))):
+                bad += 1
         for t in range(T):
-            if not (torch.equal(o[0][t], ref[0][0]) and torch.equal(o[1][t], ref[1][0])):
+            if not (torch.equal(o[0][t], first[0]) and torch.equal(o[1][t], first[1])):
                 bad += 1
 print("soak: %d runs x %d streams x %d frames, mismatching frames: %d" % (REPS, STREAMS, T, bad))
 sys.exit(1 if bad else 0)
