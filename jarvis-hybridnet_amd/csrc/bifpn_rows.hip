@@ -20,7 +20,8 @@
 // The kernel is bound by instruction issue, not by memory (three inputs run as fast as two): per row and wave
 // 56 MFMAs x 32 cycles + ~100 packed FMAs + 40 exp / rcp + ~40 LDS and 14 memory instructions ~ 5 000 cycles,
 // which is what it measures (a SIMD issues one stream, times add).  P3 node of the bench
-// (384 images 64 x 64): 273.6 -> 204.5 us, head 304 -> 219.5 us.
+// (384 images 64 x 64): 273.6 -> 194 us, head 304 -> 221 us.
+#include <algorithm>
 #include <type_traits>
 
 #include "conv_mfma.h"
@@ -319,10 +320,13 @@ bool bifpn_rows_eligible(const NodeArgs& a) {
 
 int launch_bifpn_rows(const NodeArgs& a, hipStream_t s) {
   const int strips = a.W / 16;
-  // Rows per workgroup: a function of the image size ONLY -- the float partial sums of the statistics are taken per
-  // strip segment, so the segmentation must not depend on how many images a launch carries (bit-equal results
-  // for any number of cameras per rank).  16 rows: 1.125 x fusion work; 8 for the smaller levels (more workgroups).
-  int seg_rows = JH_ENV_KNOB("JH_NODE_SEG") > 0 ? JH_ENV_KNOB("JH_NODE_SEG") : (a.H >= 64 ? 16 : 8);
+  // Rows per workgroup: a function of the node (image size, number of inputs) ONLY -- the float partial sums of the
+  // statistics are taken per strip segment, so the segmentation must not depend on how many images a launch
+  // carries (bit-equal results for any number of cameras per rank).  Measured at 384 images (P3 two-input node:
+  // 8 rows 240 us, 16: 205, 32: 191; P4: 8: 74, 16: 66, 32: 71; three-input head: 16: 221, 32: 223): half the
+  // image height for two inputs, 16 / 8 rows for three.
+  int seg_rows = JH_ENV_KNOB("JH_NODE_SEG") > 0 ? JH_ENV_KNOB("JH_NODE_SEG")
+                 : (a.n_in == 2 ? std::max(8, a.H / 2) : (a.H >= 64 ? 16 : 8));
   seg_rows = (seg_rows + 1) & ~1;                // (even: the kernel's row loop is unrolled by two on row parity)
   if (seg_rows > a.H) seg_rows = a.H;
   const int segs = (a.H + seg_rows - 1) / seg_rows;
