@@ -19,10 +19,14 @@ struct NodeArgs {
   int N, H, W, Cp, cout_p, cout_p16, cf;
   int blds = 0;            // pointwise weights staged in LDS behind the operand tile
   int alias = 0;           // operand tile written over the halo tile (single channel chunk)
+  float* y_pool = nullptr; // row-streaming form, two inputs: also the 2x2-max-pooled raw output [N][H/2][W/2][cout_p]
   int rows = -1;           // row-streaming form (bifpn_rows.hip): 1 wherever the shape allows, 0 never, -1 by launch size
   int abl = 0;             // ablation bits for timing experiments (0 in production)   // cf = channels per halo chunk (multiple of 4)
 };
 
+
+// csrc/bifpn_rows.hip: will this node take the row-streaming form?  (host; also used when a plan is built)
+bool bifpn_rows_eligible(const NodeArgs& a);
 
 #if defined(__HIPCC__)
 constexpr int kNodeTY = 8, kNodeTX = 16, kNodePY = 10, kNodePX = 18, kNodeNRG = 4;

@@ -37,8 +37,9 @@ typedef float rf4 __attribute__((ext_vector_type(4)));
 typedef unsigned ru4 __attribute__((ext_vector_type(4)));
 }  // namespace
 
-template <int NIN, int M1, int M2, int ACT>
+template <int NIN, int M1, int M2, int ACT, bool POOL = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void bifpn_rows_kernel(const NodeArgs a, int seg_rows, int strips) {
+  static_assert(!POOL || NIN == 2, "the pooled row is parked in the (unused) depthwise-weight region of the LDS");
   constexpr int kModes[3] = {FUSE_SAME, M1, M2};
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // byte offsets inside the wave's LDS: ring of three fused rows, operand block, depthwise weights
@@ -140,6 +141,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   // fused, so about two rows per wave are outstanding at any time -- the kernel is bound by bytes in flight, not by
   // instruction issue; three inputs only fit one set).
   constexpr int DEPTH = 1;
+  // POOL: the node also writes MaxPool2d(2, 2) of its raw output (the bottom-up node of the next level then reads a
+  // same-resolution tensor instead of four pixels per tap; max commutes with the monotone InstanceNorm map, the
+  // pooled tensor keeps this node's statistics).  Horizontal max: the neighbour pixel is lane ^ 1 (one DPP
+  // move); vertical: the even row's maxima wait in LDS (the depthwise-weight region, free with two inputs) for
+  // the odd row.  Lanes of even pixels own the pooled pixel.
+  __amdgpu_buffer_rsrc_t rp = ry;
+  int pbase = (int)0x80000000;                    // offset of this lane's pooled pixel (bit 31: not an owner)
+  if (POOL) {
+    rp = __builtin_amdgcn_make_buffer_rsrc(a.y_pool + (size_t)n * (a.H >> 1) * (a.W >> 1) * a.cout_p, 0,
+                                           (int)((size_t)(a.H >> 1) * (a.W >> 1) * a.cout_p * 4), 0x00020000);
+    if (!(mrow & 1)) pbase = (((ox0 + mrow) >> 1) * a.cout_p + kq * 4) * 4;
+  }
+  const int pool_lds = kDwOff + ((mrow >> 1) * kRC + kq * 4) * 4;          // + 64 * cb (channels < 56 only)
   rf4 raw[DEPTH][NIN][5];
   // An up-sampled input changes its source row only every 2nd output row: when the requested row is ODD its
   // registers are simply kept (5 load instructions less).  `all_c` is a compile-time flag -- the row loop is
@@ -221,7 +235,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       }
       // (two inputs: all four pixels at once, 18 row reads; three inputs: two pixels at a time, 24 reads but half
       //  the live registers)
-      constexpr int PXN = kDwReg ? 4 : 2;
+      constexpr int PXN = (kDwReg && !POOL) ? 4 : 2;        // (the pooled-output variant has no registers to spare)
 #pragma unroll
       for (int part = 0; part < 4 / PXN; ++part) {
         rf4 d[PXN];
@@ -266,6 +280,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       s1[cb] += v;
       s2[cb] = __builtin_elementwise_fma(v, v, s2[cb]);
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ru4, v), ry, yoff[cb] + yrow, 0, 0);
+      if (POOL) {
+        rf4 hm;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          hm[j] = fmaxf(v[j], __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v[j]), 0xB1, 0xF, 0xF, true)));
+        const bool own = !(mrow & 1) && cb * 16 + kq * 4 < kRC;             // (cout == 56: checked by the launcher)
+        if (decltype(next_all_c)::value) {                                  // even output row: park
+          if (own) *reinterpret_cast<rf4*>(smem + pool_lds + cb * 64) = hm;
+        } else {                                                            // odd row: combine, store
+          rf4 pv = hm;
+          if (own) pv = *reinterpret_cast<const rf4*>(smem + pool_lds + cb * 64);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) pv[j] = fmaxf(pv[j], hm[j]);
+          // (cout_p == 56: the last column block holds 8 channels, lanes kq >= 2 store nothing)
+          const int po = (cb == 3 && kq >= 2) ? (int)0x80000000 : pbase + cb * 64;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ru4, pv), rp,
+                                                 po + (y >> 1) * (a.W >> 1) * a.cout_p * 4, 0, 0);
+        }
+      }
     }
   };
   using C0 = std::integral_constant<int, 0>;
@@ -315,7 +348,8 @@ bool bifpn_rows_eligible(const NodeArgs& a) {
     if ((a.W / 16) * ((a.H + 7) / 8) * a.N < min_wg) return false;
   }
   if (a.n_in == 2) return a.mode[1] == FUSE_UP2;
-  return a.n_in == 3 && a.mode[1] == FUSE_UP2 && a.mode[2] == FUSE_UP4;
+  return a.n_in == 3 && ((a.mode[1] == FUSE_UP2 && a.mode[2] == FUSE_UP4) ||
+                         (a.mode[1] == FUSE_SAME && a.mode[2] == FUSE_SAME));
 }
 
 int launch_bifpn_rows(const NodeArgs& a, hipStream_t s) {
@@ -323,24 +357,30 @@ int launch_bifpn_rows(const NodeArgs& a, hipStream_t s) {
   // Rows per workgroup: a function of the node (image size, number of inputs) ONLY -- the float partial sums of the
   // statistics are taken per strip segment, so the segmentation must not depend on how many images a launch
   // carries (bit-equal results for any number of cameras per rank).  Measured at 384 images (P3 two-input node:
-  // 8 rows 240 us, 16: 205, 32: 191; P4: 8: 74, 16: 66, 32: 71; three-input head: 16: 221, 32: 223): half the
-  // image height for two inputs, 16 / 8 rows for three.
+  // 8 rows 240 us, 16: 205, 32: 191; P4: 8: 74, 16: 66, 32: 71; three-input head: 16: 221, 32: 223; three
+  // same-level inputs at P4: 8: 116, 16: 99): half the image height, 16 / 8 rows for the head.
   int seg_rows = JH_ENV_KNOB("JH_NODE_SEG") > 0 ? JH_ENV_KNOB("JH_NODE_SEG")
-                 : (a.n_in == 2 ? std::max(8, a.H / 2) : (a.H >= 64 ? 16 : 8));
+                 : (a.n_in == 2 || a.mode[1] == FUSE_SAME ? std::max(8, a.H / 2) : (a.H >= 64 ? 16 : 8));
   seg_rows = (seg_rows + 1) & ~1;                // (even: the kernel's row loop is unrolled by two on row parity)
   if (seg_rows > a.H) seg_rows = a.H;
   const int segs = (a.H + seg_rows - 1) / seg_rows;
   const size_t lds = (size_t)(3 * kRPX * kRC + kAFloats + 9 * kRC + 64) * sizeof(float);
   const dim3 grid(strips * segs, a.N);
-#define JH_ROWS(NIN, M1, M2, ACT) \
-  hipLaunchKernelGGL((bifpn_rows_kernel<NIN, M1, M2, ACT>), grid, dim3(64), lds, s, a, seg_rows, strips)
+#define JH_ROWS(NIN, M1, M2, ACT, POOL) \
+  hipLaunchKernelGGL((bifpn_rows_kernel<NIN, M1, M2, ACT, POOL>), grid, dim3(64), lds, s, a, seg_rows, strips)
+  JH_REQUIRE(!a.y_pool || (a.n_in == 2 && a.act == ACT_SILU && a.cout_p == kRC && a.H % 2 == 0),
+             "row-streaming node: pooled output");
   if (a.n_in == 2) {
-    if (a.act == ACT_SILU) JH_ROWS(2, FUSE_UP2, 0, ACT_SILU);
-    else if (a.act == ACT_NONE) JH_ROWS(2, FUSE_UP2, 0, ACT_NONE);
+    if (a.act == ACT_SILU && a.y_pool) JH_ROWS(2, FUSE_UP2, 0, ACT_SILU, true);
+    else if (a.act == ACT_SILU) JH_ROWS(2, FUSE_UP2, 0, ACT_SILU, false);
+    else if (a.act == ACT_NONE) JH_ROWS(2, FUSE_UP2, 0, ACT_NONE, false);
+    else JH_REQUIRE(false, "row-streaming node: activation");
+  } else if (a.mode[1] == FUSE_SAME) {
+    if (a.act == ACT_SILU) JH_ROWS(3, FUSE_SAME, FUSE_SAME, ACT_SILU, false);
     else JH_REQUIRE(false, "row-streaming node: activation");
   } else {
-    if (a.act == ACT_SILU) JH_ROWS(3, FUSE_UP2, FUSE_UP4, ACT_SILU);
-    else if (a.act == ACT_NONE) JH_ROWS(3, FUSE_UP2, FUSE_UP4, ACT_NONE);
+    if (a.act == ACT_SILU) JH_ROWS(3, FUSE_UP2, FUSE_UP4, ACT_SILU, false);
+    else if (a.act == ACT_NONE) JH_ROWS(3, FUSE_UP2, FUSE_UP4, ACT_NONE, false);
     else JH_REQUIRE(false, "row-streaming node: activation");
   }
 #undef JH_ROWS

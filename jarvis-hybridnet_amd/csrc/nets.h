@@ -118,7 +118,8 @@ class EffTrackPlan : public Plan {
   int lateral(const ParamMap& pm, const std::string& p, int cout, const Ref& x, Ref* out);
   int pool(const Ref& x, Ref* out);
   int node(const ParamMap& pm, const std::string& conv_prefix, int n_in, const Ref* ins,
-           const int* modes, const float* w, int act, const Act& like, int cout, Ref* out);
+           const int* modes, const float* w, int act, const Act& like, int cout, Ref* out,
+           Ref* pooled = nullptr);   // pooled: also MaxPool2d(2,2) of the raw output, if the node's form can (else a.p = 0)
 };
 
 class V2VPlan : public Plan {

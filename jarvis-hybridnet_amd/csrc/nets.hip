@@ -361,7 +361,7 @@ int EffTrackPlan::pool(const Ref& x, Ref* out) {
 // block's InstanceNorm is again left to the consumers.
 int EffTrackPlan::node(const ParamMap& pm, const std::string& cp, int n_in, const Ref* ins,
                        const int* modes, const float* w, int act, const Act& like, int cout,
-                       Ref* out) {
+                       Ref* out, Ref* pooled) {
   const int cin = like.C;
   const float* dwh = nullptr;
   if (get(pm, cp + "depthwise_conv.weight", (size_t)cin * 9, &dwh)) return 1;
@@ -393,6 +393,17 @@ int EffTrackPlan::node(const ParamMap& pm, const std::string& cp, int n_in, cons
   a.N = like.N; a.H = like.H; a.W = like.W; a.Cp = like.Cp;
   a.cout_p = out->a.Cp; a.cout_p16 = cw.cout_p16;
   a.rows = node_rows;
+  if (pooled) {
+    // the row-streaming two-input form can write the 2x2-max-pooled raw output on the side (bifpn_rows.hip): the
+    // bottom-up node of the next level then reads a same-resolution tensor with THIS node's statistics
+    pooled->a = Act{};
+    if (n_in == 2 && act == ACT_SILU && out->a.Cp == 56 && like.H % 2 == 0 && bifpn_rows_eligible(a)) {
+      if (new_act(like.N, 1, like.H / 2, like.W / 2, cout, &pooled->a)) return 1;
+      pooled->st = (long)st; pooled->inv = out->inv; pooled->act = out->act;
+      a.y_pool = pooled->a.p;
+      bytes += 4.0 * like.N * pooled->a.pixels() * cout;
+    }
+  }
   const double px = (double)like.N * like.pixels();
   char nm[64];
   snprintf(nm, sizeof nm, "bifpn_node_%dx%d@%d", cin, cout, like.W);
@@ -487,12 +498,12 @@ int EffTrackPlan::build(const ParamMap& pm, const std::string& pre, int size, in
       p4_in2 = p4; p5_in2 = p5;
     }
     auto fnode = [&](const char* wname, int n_in, const Ref* ins, const int* modes, const Ref& like,
-                     const char* conv, Ref* out) -> int {
+                     const char* conv, Ref* out, Ref* pooled = nullptr) -> int {
       const float* wp = nullptr;
       if (get(pm, p + wname, n_in, &wp)) return 1;
       float w[3];
       fuse_weights(wp, n_in, w);
-      return node(pm, p + conv + ".", n_in, ins, modes, w, ACT_SILU, like.a, Wf, out);
+      return node(pm, p + conv + ".", n_in, ins, modes, w, ACT_SILU, like.a, Wf, out, pooled);
     };
     const int m_up[2] = {FUSE_SAME, FUSE_UP2};
     const int m_dn3[3] = {FUSE_SAME, FUSE_SAME, FUSE_POOL2};
@@ -501,8 +512,16 @@ int EffTrackPlan::build(const ParamMap& pm, const std::string& pre, int size, in
     { const Ref in[2] = {p6_in, p7_in}; if (fnode("p6_w1", 2, in, m_up, p6_in, "conv6_up", &p6_up)) return 1; }
     { const Ref in[2] = {p5_in, p6_up}; if (fnode("p5_w1", 2, in, m_up, p5_in, "conv5_up", &p5_up)) return 1; }
     { const Ref in[2] = {p4_in, p5_up}; if (fnode("p4_w1", 2, in, m_up, p4_in, "conv4_up", &p4_up)) return 1; }
-    { const Ref in[2] = {p3_in, p4_up}; if (fnode("p3_w1", 2, in, m_up, p3_in, "conv3_up", &p3_out)) return 1; }
-    { const Ref in[3] = {p4_in2, p4_up, p3_out}; if (fnode("p4_w2", 3, in, m_dn3, p4_in2, "conv4_down", &p4_out)) return 1; }
+    Ref p3_pool;
+    { const Ref in[2] = {p3_in, p4_up}; if (fnode("p3_w1", 2, in, m_up, p3_in, "conv3_up", &p3_out, &p3_pool)) return 1; }
+    if (p3_pool.a.p) {          // (time batches: P3's node wrote its pooled output, all three inputs at P4's resolution)
+      const int m_same3[3] = {FUSE_SAME, FUSE_SAME, FUSE_SAME};
+      const Ref in[3] = {p4_in2, p4_up, p3_pool};
+      if (fnode("p4_w2", 3, in, m_same3, p4_in2, "conv4_down", &p4_out)) return 1;
+    } else {
+      const Ref in[3] = {p4_in2, p4_up, p3_out};
+      if (fnode("p4_w2", 3, in, m_dn3, p4_in2, "conv4_down", &p4_out)) return 1;
+    }
     { const Ref in[3] = {p5_in2, p5_up, p4_out}; if (fnode("p5_w2", 3, in, m_dn3, p5_in2, "conv5_down", &p5_out)) return 1; }
     // the head reads p3, p4, p5 of the last cell only: its p6 / p7 outputs are dead
     if (cell + 1 < ss.cells) {

@@ -199,6 +199,7 @@ NODE_CASES = [  # (C, Cout, H, W, modes, act, n): the node shapes of the small /
     (56, 64, 64, 64, (0, 1, 2), 0, 64),     # head (three inputs, no activation, 64 output channels)
     (56, 56, 32, 32, (0, 1), 2, 256),       # P4 top-down, 8-row segments
     (56, 56, 48, 32, (0, 1), 2, 192),       # height that is not a power of two
+    (56, 56, 32, 32, (0, 0, 0), 2, 256),    # P4 bottom-up when P3's node has written its pooled output: three same-level inputs
 ]
 
 
