@@ -544,6 +544,10 @@ int launch_bifpn_node(const NodeArgs& args, hipStream_t s) {
     return launch_node_variant<3, FUSE_SAME, FUSE_SAME, FUSE_POOL2>(a, lds, s);
   if (a.n_in == 3 && m1 == FUSE_UP2 && m2 == FUSE_UP4)
     return launch_node_variant<3, FUSE_SAME, FUSE_UP2, FUSE_UP4>(a, lds, s);
+  // (bottom-up node whose finer-level input arrives pooled -- written by that level's row node -- but which is
+  //  itself too small for the row form)
+  if (a.n_in == 3 && m1 == FUSE_SAME && m2 == FUSE_SAME)
+    return launch_node_variant<3, FUSE_SAME, FUSE_SAME, FUSE_SAME>(a, lds, s);
   JH_REQUIRE(false, "unsupported BiFPN node variant");
 }
 

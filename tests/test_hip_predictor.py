@@ -130,6 +130,34 @@ def _time_batch_at_bench_scale(strict):
         assert float((out[1][0] - ref[1][0]).abs().max()) <= 1e-5
 
 
+def test_time_batch_small_center_image():
+    """CenterDetect at 128 x 128: its P3 level (32 x 32) takes the row-streaming node form and writes the pooled
+    output, its P4 level (16 x 16) is too small for it -- the tile kernel then reads three same-level inputs.
+    T = 8 identical frame sets: equal bits for every frame, the single-frame call's result to 1e-4 mm."""
+    from jarvis_hybridnet_amd._predictor import NativePredictor
+    from jarvis_hybridnet_amd import synthetic as S
+    c = cases.PREDICTOR_CASES["cfg2"]
+    inp = cases.predictor_inputs("cfg2")
+    T = 8
+    kw = dict(num_cameras=c["C"], num_joints=c["J"], center_size=128, bbox=c["bbox"],
+              roi_cube_size=c["roi"], grid_spacing=c["spacing"], img_h=c["H"], img_w=c["W"],
+              mean=S.MEAN, std=S.STD)
+    dev = [cuda(t) for t in (inp["cam"], inp["intr"], inp["dist"])]
+    one = cuda(inp["imgs"]).unsqueeze(0).contiguous()
+    p1 = NativePredictor(inp["sd_center"], inp["sd_hybrid"], time_batch=1, **kw)
+    p1.set_calibration(*dev)
+    ref = [t.clone() for t in p1.forward(one)]
+    pT = NativePredictor(inp["sd_center"], inp["sd_hybrid"], time_batch=T, **kw)
+    pT.set_calibration(*dev)
+    out = [t.clone() for t in pT.forward(one.expand(T, *one.shape[1:]).contiguous())]
+    torch.cuda.synchronize()
+    assert int(ref[2][0]) == 1 and bool((out[2] == 1).all())
+    for t in range(T):
+        assert torch.equal(out[0][t], out[0][0]) and torch.equal(out[1][t], out[1][0]), t
+    assert float((out[0][0] - ref[0][0]).abs().max()) <= 1e-4
+    assert float((out[1][0] - ref[1][0]).abs().max()) <= 1e-5
+
+
 def test_time_batch_at_bench_scale():
     """16 frame sets of configs[2] in one call (192 images per 2D network launch: several workgroups
     resident per CU, thousands per launch -- the regime bench.py runs in) give, for every frame, the same bits,
