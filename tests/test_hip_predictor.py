@@ -130,16 +130,19 @@ def _time_batch_at_bench_scale(strict):
         assert float((out[1][0] - ref[1][0]).abs().max()) <= 1e-5
 
 
-def test_time_batch_small_center_image():
-    """CenterDetect at 128 x 128: its P3 level (32 x 32) takes the row-streaming node form and writes the pooled
-    output, its P4 level (16 x 16) is too small for it -- the tile kernel then reads three same-level inputs.
+@pytest.mark.parametrize("center,bbox", [(128, 256), (192, 192), (320, 320)])
+def test_time_batch_other_geometries(center, bbox):
+    """Image sizes whose pyramid levels mix the node forms.  CenterDetect at 128 x 128: its P3 level (32 x 32) takes
+    the row-streaming form and writes the pooled output, its P4 level (16 x 16) is too small for it -- the tile
+    kernel then reads three same-level inputs.  192: P3 = 48 wide (3 strips), P4 = 24 (not a multiple of 16: tile
+    form).  320: P3 = 80 x 80 (5 strips, 40-row segments), P4 = 40 (tile form).
     T = 8 identical frame sets: equal bits for every frame, the single-frame call's result to 1e-4 mm."""
     from jarvis_hybridnet_amd._predictor import NativePredictor
     from jarvis_hybridnet_amd import synthetic as S
     c = cases.PREDICTOR_CASES["cfg2"]
     inp = cases.predictor_inputs("cfg2")
     T = 8
-    kw = dict(num_cameras=c["C"], num_joints=c["J"], center_size=128, bbox=c["bbox"],
+    kw = dict(num_cameras=c["C"], num_joints=c["J"], center_size=center, bbox=bbox,
               roi_cube_size=c["roi"], grid_spacing=c["spacing"], img_h=c["H"], img_w=c["W"],
               mean=S.MEAN, std=S.STD)
     dev = [cuda(t) for t in (inp["cam"], inp["intr"], inp["dist"])]
