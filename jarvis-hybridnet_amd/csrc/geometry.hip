@@ -88,23 +88,37 @@ int launch_preprocess_crop(const void* frames, int src_u8, const int* center_hm,
 // --------------------------------------------------------------- centre argmax
 // heat: [N][Hh][Wh][Cp], channel 0.  det[n] = (x, y, maxval); first maximum wins
 // (torch.argmax on CPU returns the lowest index among equal maxima).
-__global__ __launch_bounds__(256) void center_argmax_kernel(const float* __restrict__ heat,
+__global__ __launch_bounds__(1024) void center_argmax_kernel(const float* __restrict__ heat,
                                                             float* __restrict__ det, int Hh,
                                                             int Wh, int Cp) {
-  __shared__ float sv[256];
-  __shared__ int si[256];
+  __shared__ float sv[1024];
+  __shared__ int si[1024];
   const int n = blockIdx.x;
   const int P = Hh * Wh;
   const float* h = heat + (size_t)n * P * Cp;
   float best = -INFINITY;
   int bi = 0x7fffffff;
-  for (int p = threadIdx.x; p < P; p += blockDim.x) {
+  // (eight independent loads in flight per thread: the scan is a chain of load latencies otherwise -- 26 us for
+  //  a 256 x 256 map; the compares keep the ascending-index order, so the first maximum still wins)
+  constexpr int U = 8;
+  int p = threadIdx.x;
+  for (; p + (U - 1) * (int)blockDim.x < P; p += U * blockDim.x) {
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = h[(size_t)(p + u * blockDim.x) * Cp];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int pp = p + u * blockDim.x;
+      if (v[u] > best || (v[u] == best && pp < bi)) { best = v[u]; bi = pp; }
+    }
+  }
+  for (; p < P; p += blockDim.x) {
     const float v = h[(size_t)p * Cp];
     if (v > best || (v == best && p < bi)) { best = v; bi = p; }
   }
   sv[threadIdx.x] = best; si[threadIdx.x] = bi;
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
+  for (int s = 512; s > 0; s >>= 1) {
     if (threadIdx.x < s) {
       const float v = sv[threadIdx.x + s];
       const int ii = si[threadIdx.x + s];
@@ -125,7 +139,7 @@ __global__ __launch_bounds__(256) void center_argmax_kernel(const float* __restr
 
 int launch_center_argmax(const float* heat, float* det, int N, int Hh, int Wh, int Cp,
                          hipStream_t s) {
-  hipLaunchKernelGGL(center_argmax_kernel, dim3(N), dim3(256), 0, s, heat, det, Hh, Wh, Cp);
+  hipLaunchKernelGGL(center_argmax_kernel, dim3(N), dim3(1024), 0, s, heat, det, Hh, Wh, Cp);
   JH_CHECK_HIP(hipGetLastError());
   return 0;
 }
