@@ -363,8 +363,11 @@ int jh_predictor_create(const jh_params* center_params, const jh_params* hybrid_
   if (m.get(reinterpret_cast<void**>(&pr->valid), (size_t)T * sizeof(int))) return 1;
   if (m.get(reinterpret_cast<void**>(&pr->coarse),
             (size_t)pr->T3 * C * pr->Gh * pr->Gh * pr->Gh * sizeof(float2))) return 1;
-  if (m.get(reinterpret_cast<void**>(&pr->sa_partial), (size_t)T * pr->Jp * 4 * kLimbs * sizeof(double))) return 1;
-  if (m.get(reinterpret_cast<void**>(&pr->sa_max), (size_t)T * pr->Jp * sizeof(int))) return 1;
+  {   // soft-argmax accumulators and maxima in ONE allocation (zeroed by one launch per forward)
+    const size_t pb = (size_t)T * pr->Jp * 4 * kLimbs * sizeof(double), mb = (size_t)T * pr->Jp * sizeof(int);
+    if (m.get(reinterpret_cast<void**>(&pr->sa_partial), pb + mb)) return 1;
+    pr->sa_max = reinterpret_cast<int*>(reinterpret_cast<char*>(pr->sa_partial) + pb);
+  }
   JH_CHECK_HIP(hipMemset(pr->valid, 0, (size_t)T * sizeof(int)));
   // graph replay: by default for the single-frame-set call (T = 1), where the forward is
   // launch-bound; JH_GRAPH=1 / 0 forces it on / off for every time batch

@@ -483,8 +483,13 @@ int launch_softargmax(const float* x, const int* center3d, double* partial, int*
   const int q = Jp / 4;
   JH_REQUIRE(q >= 1 && q <= 64 && J <= 256, "soft-argmax joint count");
   const int rows = 256 / q;
-  if (launch_zero(partial, (size_t)T * Jp * 4 * kLimbs * sizeof(double), s)) return 1;
-  if (launch_zero(pmax, (size_t)T * Jp * sizeof(int), s)) return 1;
+  const size_t pbytes = (size_t)T * Jp * 4 * kLimbs * sizeof(double), mbytes = (size_t)T * Jp * sizeof(int);
+  if (reinterpret_cast<char*>(pmax) == reinterpret_cast<char*>(partial) + pbytes) {
+    if (launch_zero(partial, pbytes + mbytes, s)) return 1;      // (one launch: the predictor allocates them as one)
+  } else {
+    if (launch_zero(partial, pbytes, s)) return 1;
+    if (launch_zero(pmax, mbytes, s)) return 1;
+  }
   const int ppb = rows * 8;
   dim3 grid((P + ppb - 1) / ppb, T);
   hipLaunchKernelGGL(softargmax_partial_kernel, grid, dim3(256), (size_t)rows * q * 20 * sizeof(float),
