@@ -130,6 +130,34 @@ def _time_batch_at_bench_scale(strict):
         assert float((out[1][0] - ref[1][0]).abs().max()) <= 1e-5
 
 
+def test_predictor3d_time_batch_of_distinct_frames_row_nodes():
+    """Twelve DISTINCT seeded frame sets (different subjects, crop windows, grid centres) in one call of a
+    time_batch = 12 predictor -- the class whose P3 / P4 BiFPN nodes run in the row-streaming form -- against twelve
+    single-frame calls (tile form): the same validity, 3D keypoints within 1e-4 mm (measured ~2e-5: the two node
+    forms group the fp32 partial sums of the InstanceNorm statistics differently), confidences within 1e-5."""
+    from jarvis_hybridnet_amd import synthetic as S
+    from jarvis_hybridnet_amd.prediction.jarvis3D import JarvisPredictor3D
+    c = cases.PREDICTOR_CASES["cfg2"]
+    inp = cases.predictor_inputs("cfg2")
+    calib = (inp["cam"], inp["intr"], inp["dist"])
+    frames = [inp["imgs"]] + [S.blob_frames(calib, c["W"], c["H"], c["J"], s)[0] for s in range(60, 71)]
+    pred = JarvisPredictor3D(make_cfg(c, c["center_size"]), inp["sd_center"], inp["sd_hybrid"])
+    dev = [cuda(t) for t in calib]
+    singles = [pred(cuda(f), *dev) for f in frames]
+    singles = [(None, None) if p is None else (p.clone(), q.clone()) for p, q in singles]
+    pts, conf, valid = pred.forward_batch(cuda(torch.stack(frames)), *dev)
+    torch.cuda.synchronize()
+    worst = 0.0
+    assert sum(p is not None for p, _ in singles) >= 8
+    for t, (p, q) in enumerate(singles):
+        assert int(valid[t]) == (p is not None)
+        if p is not None:
+            worst = max(worst, float((pts[t] - p[0]).abs().max()))
+            assert float((conf[t] - q[0]).abs().max()) <= 1e-5
+    report("predictor3d_time_batch_rows", frames=len(frames), points_mm=worst)
+    assert worst <= 1e-4
+
+
 @pytest.mark.parametrize("center,bbox", [(128, 256), (192, 192), (320, 320)])
 def test_time_batch_other_geometries(center, bbox):
     """Image sizes whose pyramid levels mix the node forms.  CenterDetect at 128 x 128: its P3 level (32 x 32) takes
