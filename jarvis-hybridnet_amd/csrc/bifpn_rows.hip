@@ -20,7 +20,8 @@
 // The kernel is bound by instruction issue, not by memory (three inputs run as fast as two): per row and wave
 // 56 MFMAs x 32 cycles + ~100 packed FMAs + 40 exp / rcp + ~40 LDS and 14 memory instructions ~ 5 000 cycles,
 // which is what it measures (a SIMD issues one stream, times add).  P3 node of the bench
-// (384 images 64 x 64): 273.6 -> 194 us, head 304 -> 221 us.
+// (384 images 64 x 64): 273.6 -> 194 us (219 us when it also writes its 2 x 2 max-pooled output, which lets the P4
+// bottom-up node run in this form with three same-level inputs: 151 -> 99 us), head 304 -> 221 us.
 #include <algorithm>
 #include <type_traits>
 
@@ -137,10 +138,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   for (int cb = 0; cb < 4; ++cb)
     yoff[cb] = cb * 16 + kq * 4 < a.cout_p ? ((ox0 + mrow) * a.cout_p + cb * 16 + kq * 4) * 4 : (int)0x80000000;
 
-  // Raw rows in flight: DEPTH register sets (2 for two inputs: the loads of row yf + 2 go out as soon as row yf is
-  // fused, so about two rows per wave are outstanding at any time -- the kernel is bound by bytes in flight, not by
-  // instruction issue; three inputs only fit one set).
-  constexpr int DEPTH = 1;
+  // (one raw row in flight per wave: a second register set -- loads of row yf + 2 behind the fusion of row yf -- was
+  //  slower, 274 us, the kernel is bound by instruction issue and the registers it costs forced re-loads)
   // POOL: the node also writes MaxPool2d(2, 2) of its raw output (the bottom-up node of the next level then reads a
   // same-resolution tensor instead of four pixels per tap; max commutes with the monotone InstanceNorm map, the
   // pooled tensor keeps this node's statistics).  Horizontal max: the neighbour pixel is lane ^ 1 (one DPP
@@ -154,13 +153,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (!(mrow & 1)) pbase = (((ox0 + mrow) >> 1) * a.cout_p + kq * 4) * 4;
   }
   const int pool_lds = kDwOff + ((mrow >> 1) * kRC + kq * 4) * 4;          // + 64 * cb (channels < 56 only)
-  rf4 raw[DEPTH][NIN][5];
+  rf4 raw[NIN][5];
   // An up-sampled input changes its source row only every 2nd output row: when the requested row is ODD its
   // registers are simply kept (5 load instructions less).  `all_c` is a compile-time flag -- the row loop is
   // unrolled by two -- because a load under a run-time branch makes the compiler's in-order wait counts
   // pessimistic (the fusion then also waits for the previous row's stores: 216 -> 326 us).
-  auto issue = [&](int yf, auto set_c, auto all_c) __attribute__((always_inline)) {       // (yf inside the image)
-    constexpr int set = decltype(set_c)::value;
+  auto issue = [&](int yf, auto all_c) __attribute__((always_inline)) {       // (yf inside the image)
     constexpr bool all = decltype(all_c)::value;
     int srow[NIN];
 #pragma unroll
@@ -175,12 +173,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
       for (int k = 0; k < NIN; ++k)
         if (all || kModes[k] == FUSE_SAME)
-          raw[set][k][it] =
+          raw[k][it] =
               __builtin_bit_cast(rf4, __builtin_amdgcn_raw_buffer_load_b128(rs[k], voff[k][it], srow[k], 0));
   };
   // fused + activated row yf -> ring slot (yf + 1) % 3 (zeros outside the image: the depthwise padding)
-  auto fuse = [&](int yf, int slot, auto set_c) __attribute__((always_inline)) {
-    constexpr int set = decltype(set_c)::value;
+  auto fuse = [&](int yf, int slot) __attribute__((always_inline)) {
     unsigned char* dst = smem + slot * kRowB + fdst;
     if ((unsigned)yf >= (unsigned)a.H) {                             // (uniform) padding row
 #pragma unroll
@@ -193,7 +190,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     for (int it = 0; it < 5; ++it) {
       rf4 v = bb;
 #pragma unroll
-      for (int k = 0; k < NIN; ++k) v = __builtin_elementwise_fma(raw[set][k][it], ak[k], v);
+      for (int k = 0; k < NIN; ++k) v = __builtin_elementwise_fma(raw[k][it], ak[k], v);
       if (ACT == ACT_SILU) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = v[j] * __builtin_amdgcn_rcpf(1.f + __expf(-v[j]));
@@ -216,10 +213,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   __builtin_amdgcn_s_waitcnt(0);
   int slot = (y_begin + 3) % 3;                    // slot of row yf = y_begin - 1: (yf + 1) % 3
 
-  auto row = [&](int yf, auto set_c, auto next_all_c, auto out_c) __attribute__((always_inline)) {
-    fuse(yf, slot, set_c);
-    // (this set's registers are free again: request the row DEPTH ahead)
-    if (yf + DEPTH <= y_end && yf + DEPTH < a.H) issue(yf + DEPTH, set_c, next_all_c);
+  auto row = [&](int yf, auto next_all_c, auto out_c) __attribute__((always_inline)) {
+    fuse(yf, slot);
+    // (the raw registers are free again: request the next row)
+    if (yf + 1 <= y_end && yf + 1 < a.H) issue(yf + 1, next_all_c);
     const int y = yf - 1;                               // output row whose three ring rows are now complete
     const int s_top = slot == 0 ? 1 : (slot == 1 ? 2 : 0);          // slot of row y - 1 = (slot + 1) % 3
     slot = s_top;                                 // (the next fused row replaces row y - 1 after this iteration)
@@ -301,20 +298,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       }
     }
   };
-  using C0 = std::integral_constant<int, 0>;
-  using C1 = std::integral_constant<int, DEPTH - 1>;
   // (segments start on even rows -- launch_bifpn_rows -- so row y_begin - 1 is odd and the rows requested from the
   //  first half of the unrolled body are even: all inputs; from the second half odd: same-level inputs only)
-  if (y_begin - 1 >= 0) issue(y_begin - 1, C0{}, std::true_type{});
-  if (DEPTH == 2) issue(y_begin, C1{}, std::true_type{});                              // (y_begin < H always)
+  if (y_begin - 1 >= 0) issue(y_begin - 1, std::true_type{});
   // The first two fused rows produce no output yet: peeled, so that the loop body has no path without stores --
   // with one, the compiler's in-order wait counts for the loads must assume the stores were never issued and
   // every wait for a load becomes a wait for (nearly) all of them.
-  row(y_begin - 1, C0{}, std::true_type{}, std::false_type{});
-  row(y_begin, C1{}, std::integral_constant<bool, DEPTH == 2>{}, std::false_type{});
+  row(y_begin - 1, std::true_type{}, std::false_type{});
+  row(y_begin, std::false_type{}, std::false_type{});
   for (int yf = y_begin + 1; yf <= y_end; yf += 2) {
-    row(yf, C0{}, std::true_type{}, std::true_type{});
-    if (yf + 1 <= y_end) row(yf + 1, C1{}, std::integral_constant<bool, DEPTH == 2>{}, std::true_type{});
+    row(yf, std::true_type{}, std::true_type{});
+    if (yf + 1 <= y_end) row(yf + 1, std::false_type{}, std::true_type{});
   }
   if (a.stats) {
     // sum over the 16 pixel lanes of a DPP row: xor 1, xor 2 (quad permutes), half-row mirror, row mirror
