@@ -44,8 +44,10 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
                                                         const float* __restrict__ w /* [9][3][16] */,
                                                         float* __restrict__ y, double* __restrict__ stats,
                                                         int H, int W, StemSrcArgs sa) {
-  __shared__ __attribute__((aligned(16))) float4 patch[kStP * kStP];
-  __shared__ float red[16 * 256];                    // statistics: [channel][thread]
+  // (the statistics scratch lies over the patch, which is dead once every thread has its 16 sums: 19.5 instead of
+  //  35.8 KB of LDS = twice the workgroups per CU; the kernel is bound by the latency of its patch loads)
+  __shared__ __attribute__((aligned(16))) float4 patch[kStP * kStP > 16 * 64 ? kStP * kStP : 16 * 64];
+  float* red = reinterpret_cast<float*>(patch);      // statistics: [channel][thread]
   __shared__ float red2[2 * 16 * 16];
   const int tid = threadIdx.x;
   const int Ho = H >> 1, Wo = W >> 1;
@@ -119,6 +121,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
   if (stats) {
     // [channel][thread] (consecutive threads -> consecutive banks), then 16 threads per channel
     // add 16 values each, then one thread per channel adds the 16 partials: a fixed order
+    __syncthreads();                                 // (everyone is done reading the patch)
 #pragma unroll
     for (int c = 0; c < 16; ++c) red[c * 256 + tid] = in_img ? acc[c >> 1][c & 1] : 0.f;
     __syncthreads();
@@ -180,7 +183,11 @@ int launch_stem_conv_src(const StemSource& src, const Act& x, const float* w_dev
   sa.stdv = make_float3(src.stdv[0], src.stdv[1], src.stdv[2]);
   const int tiles = ((y.H + kStT - 1) / kStT) * ((y.W + kStT - 1) / kStT);
   const dim3 grid(tiles, x.N);
-#define JH_STEM(M, U) hipLaunchKernelGGL((stem_conv_kernel<M, U>), grid, dim3(256), 0, s, x.p, w_dev, y.p, stats, x.H, x.W, sa)
+  // (the fp32 resize form is bound by HBM on the frames it reads -- 2 of every 4 rows of 1280 x 1024 x 3 floats --
+  //  and loses locality with more workgroups in flight: 654 -> 711 us at eight per CU; 16 KB of unused dynamic LDS
+  //  keep it at four.  The other forms are latency-bound and want the eight.)
+  const size_t pad_f32 = JH_ENV_KNOB("JH_STEM_PAD_KB") >= 0 ? (size_t)JH_ENV_KNOB("JH_STEM_PAD_KB") * 1024 : 16384;
+#define JH_STEM(M, U) hipLaunchKernelGGL((stem_conv_kernel<M, U>), grid, dim3(256), (M == 1 && U == 0) ? pad_f32 : 0, s, x.p, w_dev, y.p, stats, x.H, x.W, sa)
   if (src.mode == 1) { if (src.src_u8) JH_STEM(1, 1); else JH_STEM(1, 0); }
   else { if (src.src_u8) JH_STEM(2, 1); else JH_STEM(2, 0); }
 #undef JH_STEM
