@@ -237,11 +237,14 @@ int launch_se_gate(const double* pool, int N, int C, int Cp, int S, float inv_hw
 // registers and produces 1 x 4 output strips, so each staged value is read from LDS
 // (k+3)/4k times per tap instead of once.  Optional InstanceNorm statistics of the
 // output are reduced in the block and added with fp64 atomics.
-template <int K>
+template <int K, int CC>
 __global__ __launch_bounds__(256) void depthwise_lds_kernel(
     const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
     double* __restrict__ stats, int H, int W, int Cp) {
-  constexpr int T = 16, HT = T + K - 1, CC = 32, SP = CC + 4;
+  constexpr int T = 16, HT = T + K - 1, SP = CC + 4;
+  constexpr int QN = CC / 4, SL = 256 / QN;         // channel quads of a chunk, pixel slots (threads per quad)
+  constexpr int QS = QN == 8 ? 3 : 2;               // log2(QN)
+  static_assert(CC == 32 || CC == 16, "channel chunk");
   extern __shared__ __attribute__((aligned(16))) float sm[];     // [HT*HT][SP], then [K*K][CC] weights
   float* wl = sm + HT * HT * SP;
   const int tid = threadIdx.x;
@@ -250,44 +253,44 @@ __global__ __launch_bounds__(256) void depthwise_lds_kernel(
   const int ox0 = (bid.x % tiles_x) * T, oy0 = (bid.x / tiles_x) * T;
   const int c0 = bid.y * CC;
   const int n = bid.z;
-  const int q = min(CC, Cp - c0) >> 2;             // channel quads in this chunk (<= 8)
+  const int q = min(CC, Cp - c0) >> 2;             // channel quads in this chunk (<= QN)
   typedef float df2 __attribute__((ext_vector_type(2)));
   typedef float df4 __attribute__((ext_vector_type(4)));
   // The kernel is latency-bound (two workgroups per CU, ~900 instructions per wave): everything it
   // needs from memory is requested in ONE round trip -- the weights of the chunk first, then the
   // whole halo patch (thread -> channel quad tid % 8, pixel slot tid / 8; pixels outside the image
   // and quads past the tensor are out-of-range buffer loads, i.e. the zero padding, no branches).
-  const int lc4 = tid & 7, slot = tid >> 3;
+  const int lc4 = tid & (QN - 1), slot = tid >> QS;
   df4 wv = (df4){0.f, 0.f, 0.f, 0.f};
-  if (tid < K * K * 8 && lc4 < q)
-    wv = *reinterpret_cast<const df4*>(w + (size_t)(tid >> 3) * Cp + c0 + lc4 * 4);
+  if (tid < K * K * QN && lc4 < q)
+    wv = *reinterpret_cast<const df4*>(w + (size_t)(tid >> QS) * Cp + c0 + lc4 * 4);
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(x + (size_t)n * H * W * Cp), 0, (int)((size_t)H * W * Cp * 4), 0x00020000);
-  constexpr int NPX = HT * HT, ITERS = (NPX + 31) / 32;
+  constexpr int NPX = HT * HT, ITERS = (NPX + SL - 1) / SL;
   df4 v[ITERS];
 #pragma unroll
   for (int u = 0; u < ITERS; ++u) {
-    const int pix = u * 32 + slot;
+    const int pix = u * SL + slot;
     const int px = pix % HT, py = pix / HT;
     const int iy = oy0 + py - K / 2, ix = ox0 + px - K / 2;
     const bool ok = pix < NPX && lc4 < q && iy >= 0 && iy < H && ix >= 0 && ix < W;
     const int off = ok ? ((iy * W + ix) * Cp + c0 + lc4 * 4) * 4 : (int)0x80000000;
     v[u] = __builtin_bit_cast(df4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
   }
-  if (tid < K * K * 8) *reinterpret_cast<df4*>(wl + (tid >> 3) * CC + lc4 * 4) = wv;
+  if (tid < K * K * QN) *reinterpret_cast<df4*>(wl + (tid >> QS) * CC + lc4 * 4) = wv;
 #pragma unroll
   for (int u = 0; u < ITERS; ++u) {
-    const int pix = u * 32 + slot;
+    const int pix = u * SL + slot;
     if (pix < NPX) *reinterpret_cast<df4*>(sm + pix * SP + lc4 * 4) = v[u];
   }
-  const int c4 = tid & 7;                          // fixed channel quad of this thread
+  const int c4 = tid & (QN - 1);                   // fixed channel quad of this thread
   const bool active = c4 < q;
   __syncthreads();
   df2 s1l = (df2){0.f, 0.f}, s1h = s1l, s2l = s1l, s2h = s1l;
   if (active) {
 #pragma unroll 1
-    for (int j = 0; j < 2; ++j) {
-      const int g = (tid >> 3) + 32 * j;           // 64 strips: 16 rows x 4 strips of 4 pixels
+    for (int j = 0; j < 64 / SL; ++j) {
+      const int g = (tid >> QS) + SL * j;          // 64 strips: 16 rows x 4 strips of 4 pixels
       const int ty = g >> 2, tx0 = (g & 3) * 4;
       df2 al[4], ah[4];                            // packed fp32 FMAs: two channels per instruction
 #pragma unroll
@@ -325,18 +328,18 @@ __global__ __launch_bounds__(256) void depthwise_lds_kernel(
   }
   if (stats) {
     __syncthreads();                               // the patch is dead: reuse LDS for the reduce
-    // [32 rows][8 quads][2][4]; fixed-order two-level sum (8 threads x 4 rows, then 8 partials)
-    df4* p = reinterpret_cast<df4*>(sm) + ((size_t)(tid >> 3) * 8 + c4) * 2;
+    // [SL rows][QN quads][2][4]; fixed-order two-level sum (8 threads x SL / 8 rows, then 8 partials)
+    df4* p = reinterpret_cast<df4*>(sm) + ((size_t)(tid >> QS) * QN + c4) * 2;
     p[0] = (df4){s1l[0], s1l[1], s1h[0], s1h[1]};
     p[1] = (df4){s2l[0], s2l[1], s2h[0], s2h[1]};
-    float* red2 = sm + 32 * 8 * 8;                 // [64 values][8 parts]
+    float* red2 = sm + SL * QN * 8;                // [QN * 8 values][8 parts]
     __syncthreads();
     for (int i = tid; i < q * 8 * 8; i += 256) {
       const int part = i & 7, val = i >> 3;        // val = (quad, sum / sum of squares, component)
       const int comp = val & 3, sq = (val >> 2) & 1, cq = val >> 3;
       float acc = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc += sm[(((size_t)(part * 4 + r) * 8 + cq) * 2 + sq) * 4 + comp];
+      for (int r = 0; r < SL / 8; ++r) acc += sm[(((size_t)(part * (SL / 8) + r) * QN + cq) * 2 + sq) * 4 + comp];
       red2[val * 8 + part] = acc;
     }
     __syncthreads();
@@ -354,14 +357,19 @@ int launch_depthwise(const Act& x, const float* w, int k, float* y, double* stat
   JH_REQUIRE(x.D == 1, "depthwise is 2D only");
   JH_REQUIRE(k == 3 || k == 5, "depthwise kernel size must be 3 or 5");
   const int tiles = ((x.H + 15) / 16) * ((x.W + 15) / 16);
-  dim3 grid(tiles, (x.Cp + 31) / 32, x.N);
+  // Channel chunk per workgroup: 16 (33.6 KB of LDS at k = 5: four workgroups per CU) unless JH_DW_CC=32 (60.8 KB,
+  // two per CU: the round-2 form).  The kernel is latency-bound; the chunk is part of no sum (statistics are
+  // per channel), so the choice does not depend on anything but the knob.
+  const int cc = JH_ENV_KNOB("JH_DW_CC") == 32 ? 32 : 16;
+  dim3 grid(tiles, (x.Cp + cc - 1) / cc, x.N);
   const int ht = 16 + k - 1;
-  size_t lds = (size_t)(ht * ht * 36 + k * k * 32) * sizeof(float);
-  if (lds < (32 * 8 * 8 + 64 * 8) * sizeof(float)) lds = (32 * 8 * 8 + 64 * 8) * sizeof(float);
-  if (k == 3)
-    hipLaunchKernelGGL(depthwise_lds_kernel<3>, grid, dim3(256), lds, s, x.p, w, y, stats, x.H, x.W, x.Cp);
-  else
-    hipLaunchKernelGGL(depthwise_lds_kernel<5>, grid, dim3(256), lds, s, x.p, w, y, stats, x.H, x.W, x.Cp);
+  size_t lds = (size_t)(ht * ht * (cc + 4) + k * k * cc) * sizeof(float);
+  const size_t red = (size_t)((256 / (cc / 4)) * (cc / 4) * 8 + (cc / 4) * 8 * 8) * sizeof(float);
+  if (lds < red) lds = red;
+#define JH_DW(K, CC) hipLaunchKernelGGL((depthwise_lds_kernel<K, CC>), grid, dim3(256), lds, s, x.p, w, y, stats, x.H, x.W, x.Cp)
+  if (k == 3) { if (cc == 32) JH_DW(3, 32); else JH_DW(3, 16); }
+  else { if (cc == 32) JH_DW(5, 32); else JH_DW(5, 16); }
+#undef JH_DW
   JH_CHECK_HIP(hipGetLastError());
   return 0;
 }
