@@ -163,7 +163,9 @@ int launch_conv(const ConvDesc& d, const ConvWeights& w, const Act& x, const Act
   conv_out_shape(d, x.D, x.H, x.W, &Do, &Ho, &Wo);
   JH_REQUIRE(Do == y.D && Ho == y.H && Wo == y.W, "conv output extent mismatch");
   const int nr = pick_nr(w.cout_p16 / 16);
-  const size_t budget = 72 * 1024;
+  // LDS budget of the staged channel chunk (pick_kc8): 40 KB -- three to four workgroups per CU for the k5 / k4T
+  // layers -- measured against 72 KB (two): k5s2 16->96 308 -> 287 us, head ConvTranspose 954 -> 928 us
+  const size_t budget = 40 * 1024;
   if (d.nd == 2 && d.ostride == 2 && d.k == 2) {      // all four parities from one staged patch
     const int rc = launch_deconv4_fused(a, s);
     if (rc >= 0) return rc;
