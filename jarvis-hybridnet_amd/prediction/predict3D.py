@@ -71,10 +71,12 @@ def predict3D_frames(predictor, frame_sets, cameraMatrices, intrinsicMatrices,
 
     time_batch > 1 groups that many consecutive frame sets into one launch sequence
     (`forward_batch`, the throughput form the bench measures); rows are written in frame
-    order and are the same as with time_batch = 1.  A short last group is padded with
-    its last frame set and the padding rows are dropped.  streams > 1 (with time_batch > 1)
-    keeps that many groups in flight on as many HIP streams; rows still come out in frame
-    order and are identical."""
+    order and are the same as with time_batch = 1 -- bit for bit up to time_batch 7, to about
+    1e-5 mm from 8 on (the high-resolution BiFPN nodes then run in their row-streaming form,
+    DESIGN.md section 1; a row does not depend on its position in the group or on `streams`).
+    A short last group is padded with its last frame set and the padding rows are dropped.
+    streams > 1 (with time_batch > 1) keeps that many groups in flight on as many HIP streams;
+    rows still come out in frame order and are identical to the streams = 1 run."""
     os.makedirs(output_dir, exist_ok=True)
     if params is not None:
         params.output_dir = output_dir
