@@ -52,6 +52,13 @@ CONFIGS = {
                  metric="multi-view frames/s (16cam 1280x1024, 30kpt, 96^3 grid)",
                  workload="BASELINE configs[4]: HybridNet 16-camera 1280x1024, 30 kpts, 96^3 grid, "
                           "small/small, batched multi-subject stream"),
+    # the one configuration the reference ships (projects/Example_Project/config.yaml:36-37: ROI_CUBE_SIZE 144,
+    # GRID_SPACING 2 => a 72^3 grid); not a BASELINE config, reported under profiles/ as a secondary workload
+    "ex72": dict(C=12, W=1280, H=1024, J=23, roi=144, spacing=2, bbox=256, center=256, focal=1800.0,
+                 time_batch=24, seeds=(50, 51, 64),
+                 metric="multi-view frames/s (12cam 1280x1024, 23kpt, 72^3 grid)",
+                 workload="reference Example_Project geometry: HybridNet 12-camera 1280x1024, 23 kpts, "
+                          "72^3 grid (ROI 144 / spacing 2), small/small"),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_16x16x32_bf16 / 32x32x16, dense
@@ -547,7 +554,7 @@ def main():
             # flips a few reprojection gather indices of the reference itself (DESIGN.md,
             # "reproducibility of the reference"); the pinned comparison is the next one.
             line["parity_max_abs_mm_vs_host_oracle"] = (res[0][0][0].cpu() - ref[0][0]).abs().max().item()
-    if rank == 0 and world == 1 and size == "small" and args.config in ("cfg3", "cfg2", "cfg5"):
+    if rank == 0 and world == 1 and size == "small" and args.config in ("cfg3", "cfg2", "cfg5", "ex72"):
         # frame 0 of this workload is a fixture case of tests/golden/predictor.npz, i.e. the
         # output of the imported upstream reference on the same input
         import numpy as np
@@ -617,7 +624,7 @@ def main():
                                 if k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms",
                                          "launches_per_step", "algorithmic_equiv")} for r in rk]}
             gpath = os.path.join(ROOT, "tests", "golden", "predictor.npz")
-            if os.path.isfile(gpath) and size == "small" and args.config in ("cfg3", "cfg2", "cfg5"):
+            if os.path.isfile(gpath) and size == "small" and args.config in ("cfg3", "cfg2", "cfg5", "ex72"):
                 import numpy as np
                 gold = np.load(gpath)[args.config + ".points3D"]
                 red["parity_max_abs_mm_vs_reference_fixture"] = float(

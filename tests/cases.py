@@ -33,6 +33,9 @@ REPRO_CASES = {
     "cfg2": (4, 23, 48, 2, 256, 640, 512, 900.0, 12),
     "cfg3": (12, 23, 64, 2, 256, 1280, 1024, 1800.0, 13),
     "cfg5": (16, 30, 96, 2, 256, 1280, 1024, 1800.0, 14),
+    # the geometry the reference ships (projects/Example_Project/config.yaml:36-37: ROI_CUBE_SIZE 144,
+    # GRID_SPACING 2 => G = 72, not a multiple of 16; repro_layer.py:18-19)
+    "ex72": (12, 23, 72, 2, 256, 1280, 1024, 1800.0, 15),
 }
 
 # tag -> (J, G, weight seed, input seed)
@@ -40,6 +43,7 @@ V2V_CASES = {
     "j3_g16": (3, 16, 20, 21),
     "j23_g48": (23, 48, 22, 23),
     "j23_g64": (23, 64, 22, 24),
+    "j23_g72": (23, 72, 22, 25),       # Example_Project geometry: V2V at 36^3 / 18^3
 }
 
 # tag -> (C, W, H, focal, seed)
@@ -56,6 +60,9 @@ HYBRID_CASES = {
     # BASELINE configs[4] geometry: 16 cameras, 30 keypoints, 96^3 grid
     "cfg5": dict(C=16, J=30, roi=192, spacing=2, bbox=256, W=1280, H=1024,
                  focal=1800.0, wseed=43, fseed=44),
+    # Example_Project geometry (ROI 144 / spacing 2: G = 72, V2V at 36^3 / 18^3)
+    "ex72": dict(C=12, J=23, roi=144, spacing=2, bbox=256, W=1280, H=1024,
+                 focal=1800.0, wseed=40, fseed=45),
 }
 
 PREDICTOR_CASES = {
@@ -77,6 +84,14 @@ PREDICTOR_CASES = {
                  W=1280, H=1024, focal=1800.0, cseed=54, hseed=55, fseed=56),
     "cfg5_b": dict(C=16, J=30, roi=192, spacing=2, bbox=256, center_size=256,
                    W=1280, H=1024, focal=1800.0, cseed=54, hseed=55, fseed=57),
+    # the one configuration the reference ships (projects/Example_Project/config.yaml: 12 cameras,
+    # ROI_CUBE_SIZE 144, GRID_SPACING 2 => a 72^3 grid)
+    "ex72": dict(C=12, J=23, roi=144, spacing=2, bbox=256, center_size=256,
+                 W=1280, H=1024, focal=1800.0, cseed=50, hseed=51, fseed=64),
+    # configs[2] with the reference's DEFAULT model size (config/config.py:37,49: 'medium')
+    "cfg3_medium": dict(C=12, J=23, roi=128, spacing=2, bbox=256, center_size=256,
+                        W=1280, H=1024, focal=1800.0, cseed=66, hseed=63, fseed=52,
+                        size="medium"),
 }
 
 
@@ -141,8 +156,9 @@ def predictor_inputs(tag):
     c = PREDICTOR_CASES[tag]
     calib = S.ring_calibration(c["C"], c["W"], c["H"], c["focal"])
     std = c.get("deconv_std", 1.2)
-    sd_c = S.efficienttrack_weights("small", 1, c["cseed"], deconv_std=std)
-    sd_h = S.hybridnet_weights("small", c["J"], c["hseed"])
+    size = c.get("size", "small")
+    sd_c = S.efficienttrack_weights(size, 1, c["cseed"], deconv_std=std)
+    sd_h = S.hybridnet_weights(size, c["J"], c["hseed"])
     imgs, joints, centre = S.blob_frames(calib, c["W"], c["H"], c["J"], c["fseed"])
     out = dict(sd_center=sd_c, sd_hybrid=sd_h, imgs=imgs, cam=calib[0],
                intr=calib[1], dist=calib[2], joints=joints, centre=centre)

@@ -7,6 +7,8 @@ every reference tensor BIT-FOR-BIT, and writes small `.npz` fixtures (full
 tensors where small, strided samples + float64 checksums where large).
 
     python tests/golden/make_golden.py [case ...]
+    GOLDEN_TAGS=ex72,cfg3_medium python tests/golden/make_golden.py predictor   # only these tags,
+                                              # merged into the existing .npz / .json of the case
 
 The fixtures are data (inputs are re-derivable from seeds; outputs are the
 reference's).  No reference source is copied into the repository.
@@ -72,8 +74,30 @@ def must_equal(a, b, what):
         raise SystemExit("oracle != reference for %s (max abs diff %g)" % (what, d))
 
 
+ONLY = set(filter(None, os.environ.get("GOLDEN_TAGS", "").split(",")))
+
+
+def tags(table):
+    """The cases of `table` to (re)generate: all, or those named in GOLDEN_TAGS."""
+    return {k: v for k, v in table.items() if not ONLY or k in ONLY}.items()
+
+
+def merge_json(name, new):
+    path = os.path.join(HERE, name)
+    if ONLY and os.path.exists(path):
+        old = json.load(open(path))
+        old.update(new)
+        new = old
+    with open(path, "w") as f:
+        json.dump(new, f, indent=1)
+
+
 def save(name, out):
     path = os.path.join(HERE, name + ".npz")
+    if ONLY and os.path.exists(path):
+        old = dict(np.load(path))
+        old.update(out)
+        out = old
     np.savez_compressed(path, **out)
     print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024))
 
@@ -121,7 +145,7 @@ def case_state_spec():
 
 def case_reprojection():
     out = {}
-    for tag, (C, J, G, spacing, bbox, W, H, focal, seed) in cases.REPRO_CASES.items():
+    for tag, (C, J, G, spacing, bbox, W, H, focal, seed) in tags(cases.REPRO_CASES):
         cfg = R.make_cfg(num_cameras=C, num_joints=J, roi=G * spacing,
                          spacing=spacing, bbox=bbox)
         inp = cases.repro_inputs(tag)
@@ -168,7 +192,7 @@ def case_reprojection_hash():
     cfg5 that are too many to commit in full (tests/util.py::index_plane_hashes)."""
     from tests.util import index_plane_hashes
     out = {}
-    for tag, (C, J, G, spacing, bbox, W, H, focal, seed) in cases.REPRO_CASES.items():
+    for tag, (C, J, G, spacing, bbox, W, H, focal, seed) in tags(cases.REPRO_CASES):
         cfg = R.make_cfg(num_cameras=C, num_joints=J, roi=G * spacing, spacing=spacing, bbox=bbox)
         inp = cases.repro_inputs(tag)
         layer = ReprojectionLayer(cfg)
@@ -178,13 +202,12 @@ def case_reprojection_hash():
                                             inp["center_hm"][0])
         out[tag] = dict(n=int(ref_idx.numel()), planes=index_plane_hashes(ref_idx))
         print(tag, tuple(ref_idx.shape), out[tag]["planes"][:2])
-    with open(os.path.join(HERE, "reprojection_index_hashes.json"), "w") as f:
-        json.dump(out, f, indent=1)
+    merge_json("reprojection_index_hashes.json", out)
 
 
 def case_v2v():
     out = {}
-    for tag, (J, G, wseed, xseed) in cases.V2V_CASES.items():
+    for tag, (J, G, wseed, xseed) in tags(cases.V2V_CASES):
         sd = S.v2v_weights(J, wseed)
         x = cases.v2v_input(J, G, xseed)
         ref = V2VNet(J, J).eval()
@@ -260,10 +283,11 @@ def _predictor(cfg, sd_center, sd_hybrid, tmp):
 def case_predictor():
     out = {}
     meta = {}
-    for tag, c in cases.PREDICTOR_CASES.items():
+    for tag, c in tags(cases.PREDICTOR_CASES):
+        size = c.get("size", "small")
         cfg = R.make_cfg(num_cameras=c["C"], num_joints=c["J"], roi=c["roi"],
                          spacing=c["spacing"], bbox=c["bbox"],
-                         center_size=c["center_size"])
+                         center_size=c["center_size"], center_model=size, kp_model=size)
         inp = cases.predictor_inputs(tag)
         with tempfile.TemporaryDirectory() as tmp:
             pred = _predictor(cfg, inp["sd_center"], inp["sd_hybrid"], tmp)
@@ -290,7 +314,7 @@ def case_predictor():
                 inp["intr"], inp["dist"], center_size=c["center_size"],
                 bbox=c["bbox"], roi_cube_size=c["roi"],
                 grid_spacing=c["spacing"], mean=S.MEAN, std=S.STD, chunk=5,
-                intermediates=inter)
+                center_model=size, kp_model=size, intermediates=inter)
         if c.get("expect_none"):
             assert pts is None and conf is None and opts is None
             out[tag + ".none"] = np.int64(1)
@@ -330,14 +354,13 @@ def case_predictor():
         put(out, tag + ".heatmap_final", seen["heatmap_final"], False)
         print(tag, "ok", pts[0, :2].tolist(), conf[0, :3].tolist())
     save("predictor", out)
-    with open(os.path.join(HERE, "predictor_meta.json"), "w") as f:
-        json.dump(meta, f, indent=1)
+    merge_json("predictor_meta.json", meta)
 
 
 def case_hybridnet():
     """HybridNetBackbone.forward with geometrically meaningful centres."""
     out = {}
-    for tag, c in cases.HYBRID_CASES.items():
+    for tag, c in tags(cases.HYBRID_CASES):
         cfg = R.make_cfg(num_cameras=c["C"], num_joints=c["J"], roi=c["roi"],
                          spacing=c["spacing"], bbox=c["bbox"])
         inp = cases.hybrid_inputs(tag)

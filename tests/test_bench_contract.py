@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_line():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1",
-                          "--time-batch", "3", "--streams", "2", "--no-cpu-baseline", "--no-uint8", "--no-secondary"],
+                          "--time-batch", "8", "--streams", "2", "--no-cpu-baseline", "--no-uint8", "--no-secondary"],
                          cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
@@ -22,19 +22,21 @@ def test_bench_line():
         assert key in line, key
     assert line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1
     assert line["vs_baseline"] is None and line["dtype"] == "f32" and line["higher_is_better"] is True
-    assert line["config"]["frames_per_step"] == 6 and line["config"]["streams"] == 2
+    assert line["config"]["frames_per_step"] == 16 and line["config"]["streams"] == 2
     r = line["roofline"]
     assert r["bound"] in ("mfma", "hbm") and r["peak"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert 0 < r["frac"] <= 1.0, "roofline.frac is a utilisation of the executed work, never above 1"
     assert line["config"]["valid_frames_per_step"] == line["config"]["frames_per_step"]
     assert len(line["kernels"]) >= 5 and all(0 < k["frac"] <= 1.0 for k in line["kernels"])
     assert {"median", "p10", "p90"} <= set(line["step_time_ms"])
-    assert line["value"] > 0 and abs(line["value"] - 6 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"] + 1e-3
+    assert line["value"] > 0 and abs(line["value"] - 16 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"] + 1e-3
     # an empty frame set inside a batch leaves its neighbours untouched
     assert line["invalid_frame_check"]["other_frames_bit_equal"] is True
     # the separately labelled reduced-precision line: its own dtype, parity against the same fixture
     rp = line["reduced_precision"]
     assert rp["mode"] == "bf16x3" and rp["value"] > 0 and rp["dtype"].startswith("bf16x3")
     assert rp["parity_max_abs_mm_vs_reference_fixture"] < 1e-3 and 0 < rp["kernels"][0]["frac"] <= 1.0
-    # frame 0 of the bench workload is the reference's own output for that input
+    # frame 0 of the bench workload is the reference's own output for that input; with --time-batch 8 the timed
+    # path is the time_batch >= 8 class (row-streaming BiFPN nodes), i.e. the form the default bench runs
     assert line["parity_max_abs_mm_vs_reference_fixture"] < 1e-3
+    assert line["config"]["time_batch"] >= 8

@@ -17,12 +17,13 @@ def make_cfg(c, center_size=256):
     from jarvis_hybridnet_amd import synthetic as S
     return NS(PARENT_DIR="/nonexistent", PROJECT_NAME="none",
               DATASET=NS(DATASET_ROOT_DIR="x", MEAN=S.MEAN, STD=S.STD),
-              CENTERDETECT=NS(MODEL_SIZE="small", NUM_JOINTS=1, IMAGE_SIZE=center_size),
-              KEYPOINTDETECT=NS(MODEL_SIZE="small", NUM_JOINTS=c["J"], BOUNDING_BOX_SIZE=c["bbox"]),
+              CENTERDETECT=NS(MODEL_SIZE=c.get("size", "small"), NUM_JOINTS=1, IMAGE_SIZE=center_size),
+              KEYPOINTDETECT=NS(MODEL_SIZE=c.get("size", "small"), NUM_JOINTS=c["J"],
+                                BOUNDING_BOX_SIZE=c["bbox"]),
               HYBRIDNET=NS(NUM_CAMERAS=c["C"], ROI_CUBE_SIZE=c["roi"], GRID_SPACING=c["spacing"]))
 
 
-@pytest.mark.parametrize("tag", ["cfg2", "cfg3", "cfg5"])
+@pytest.mark.parametrize("tag", ["cfg2", "cfg3", "cfg5", "ex72"])
 def test_hybridnet_backbone(tag, golden):
     from jarvis_hybridnet_amd.hybridnet.hybridnet import HybridNet
     c = cases.HYBRID_CASES[tag]
@@ -43,10 +44,11 @@ def test_hybridnet_backbone(tag, golden):
     check_summary(g, tag + ".heatmap_final", fin.cpu(), rtol=1e-3, atol=1e-3)
 
 
-@pytest.mark.parametrize("tag", ["cfg2", "cfg3", "cfg2_none", "cfg2_u8", "cfg5"])
+@pytest.mark.parametrize("tag", ["cfg2", "cfg3", "cfg2_none", "cfg2_u8", "cfg5", "ex72", "cfg3_medium"])
 def test_predictor3d(tag, golden):
     """JarvisPredictor3D.forward vs the imported reference's output on the same input
-    (tests/golden/predictor.npz).  cfg2_u8: the HIP path is fed the uint8 BGR bytes
+    (tests/golden/predictor.npz).  ex72 = the geometry the reference ships (Example_Project: 72^3 grid, V2V at
+    36^3 / 18^3); cfg3_medium = configs[2] with the reference's default model size.  cfg2_u8: the HIP path is fed the uint8 BGR bytes
     (forward_uint8), the reference the driver's conversion of the same bytes
     (predict3D.py:79-80).  cfg5 = BASELINE configs[4]: 16 cameras, 30 keypoints, 96^3."""
     from jarvis_hybridnet_amd.prediction.jarvis3D import JarvisPredictor3D
@@ -76,6 +78,39 @@ def test_predictor3d(tag, golden):
     report("predictor3d", tag=tag, points_mm=ep, conf=ec, center3d_mm=e3)
     assert ep < 1e-3, "3D keypoints must be within 1e-3 mm of the reference"
     assert ec < 1e-4
+
+
+@pytest.mark.parametrize("tag", ["ex72", "cfg3"])
+def test_predictor3d_time_batch_8_vs_fixture(tag, golden):
+    """The time_batch >= 8 class (row-streaming BiFPN nodes: the form bench.py times) held to the REFERENCE fixture
+    directly: frame 0 of an 8-frame-set call is the fixture case; the other seven are distinct subjects and
+    must agree with their single-frame calls.  ex72 = the reference's shipped geometry (72^3 grid: cube gather on
+    a grid that is not a multiple of 16, V2V at 36^3 / 18^3 with partial Winograd tiles)."""
+    from jarvis_hybridnet_amd import synthetic as S
+    from jarvis_hybridnet_amd.prediction.jarvis3D import JarvisPredictor3D
+    c = cases.PREDICTOR_CASES[tag]
+    inp = cases.predictor_inputs(tag)
+    calib = (inp["cam"], inp["intr"], inp["dist"])
+    frames = [inp["imgs"]] + [S.blob_frames(calib, c["W"], c["H"], c["J"], s)[0] for s in range(70, 77)]
+    pred = JarvisPredictor3D(make_cfg(c, c["center_size"]), inp["sd_center"], inp["sd_hybrid"])
+    dev = [cuda(t) for t in calib]
+    singles = [pred(cuda(f), *dev) for f in frames]
+    singles = [(None, None) if p is None else (p.clone(), q.clone()) for p, q in singles]
+    pts, conf, valid = pred.forward_batch(cuda(torch.stack(frames)), *dev)
+    torch.cuda.synchronize()
+    g = golden("predictor")
+    assert int(valid[0]) == 1
+    ep = max_err(pts[0], torch.from_numpy(g[tag + ".points3D"])[0])
+    ec = max_err(conf[0], torch.from_numpy(g[tag + ".confidences"])[0])
+    worst = 0.0
+    for t, (p, q) in enumerate(singles):
+        assert int(valid[t]) == (p is not None)
+        if p is not None:
+            worst = max(worst, float((pts[t] - p[0]).abs().max()))
+            assert float((conf[t] - q[0]).abs().max()) <= 1e-5
+    report("predictor3d_T8_vs_fixture", tag=tag, points_mm=ep, conf=ec, vs_single_calls_mm=worst)
+    assert ep < 1e-3 and ec < 1e-4, "3D keypoints must be within 1e-3 mm of the reference"
+    assert worst <= 1e-4
 
 
 def test_predictor3d_time_batch():
@@ -341,21 +376,19 @@ def test_predictor3d_multi_subject_cfg5(golden):
         assert ep < 1e-3 and ec < 1e-4
 
 
-@pytest.mark.parametrize("mode", ["alltoall", "allgather", "rank0"])
-def test_sharded_cfg3_four_ranks(mode, golden):
-    """BASELINE configs[3] on ONE GPU: the 12-camera rig sharded 3 cameras per rank over FOUR
-    emulated ranks, T = 4 frames, through the real ShardedPredictor (distributed.py) with an
-    in-process communicator (tests/local_comm.py: copies instead of RCCL).  `rank0` is the
-    literal placement of configs[3] (heatmaps all-gathered, 3D stage on rank 0).  Frame 0 is
-    fixture case cfg3 (the reference's output); all frames must equal the unsharded forward."""
+def _sharded_emulated(tag, world, T, mode, golden):
+    """The rig of predictor case `tag` sharded C / world cameras per rank over `world` emulated ranks on ONE GPU,
+    T frame sets, through the real ShardedPredictor (distributed.py) with an in-process communicator
+    (tests/local_comm.py: copies instead of RCCL).  Every rank's rows must equal the unsharded forward bit for
+    bit; frame 0 is the fixture case (the reference's own output)."""
     from jarvis_hybridnet_amd import synthetic as S
     from jarvis_hybridnet_amd._predictor import NativePredictor
     from jarvis_hybridnet_amd.distributed import ShardedPredictor, camera_range
     from tests.local_comm import LocalWorld
-    c = cases.PREDICTOR_CASES["cfg3"]
-    inp = cases.predictor_inputs("cfg3")
+    c = cases.PREDICTOR_CASES[tag]
+    inp = cases.predictor_inputs(tag)
     calib = (inp["cam"], inp["intr"], inp["dist"])
-    T, C, J, world = 4, c["C"], c["J"], 4
+    C, J = c["C"], c["J"]
     frames = cuda(torch.stack([inp["imgs"]] + [S.blob_frames(calib, c["W"], c["H"], J, 60 + t)[0]
                                                for t in range(1, T)]))
     common = dict(num_cameras=C, num_joints=J, center_size=c["center_size"], bbox=c["bbox"],
@@ -366,6 +399,7 @@ def test_sharded_cfg3_four_ranks(mode, golden):
     full.set_calibration(*dev)
     rp, rc, rv = [t.clone() for t in full.forward(frames)]
     torch.cuda.synchronize()
+    full.close()
     three_d = "rank0" if mode == "rank0" else "sharded"
     preds = []
     for r in range(world):
@@ -392,17 +426,35 @@ def test_sharded_cfg3_four_ranks(mode, golden):
         return first, again
     res = LocalWorld(world).run(rank_fn)
     torch.cuda.synchronize()
+    name = "sharded_%s_%dranks" % (tag, world)
+    assert int(rv.sum()) >= T - 1, "the case is meant to exercise the 3D branch"
     for r in range(world):
         (pts, conf, valid), again = res[r]
         assert torch.equal(valid, rv)
         ep, ec = max_err(pts, rp), max_err(conf, rc)
-        report("sharded_cfg3_4ranks", mode=mode, rank=r, points_mm=ep, conf=ec)
+        report(name, mode=mode, rank=r, points_mm=ep, conf=ec)
         assert torch.equal(pts, rp) and torch.equal(conf, rc), "sharded output must equal the 1-GPU output bit for bit"
         assert torch.equal(again[0], pts) and torch.equal(again[1], conf)
-    gold = torch.from_numpy(golden("predictor")["cfg3.points3D"])[0]
+    gold = torch.from_numpy(golden("predictor")[tag + ".points3D"])[0]
     e0 = max_err(res[0][0][0][0], gold)
-    report("sharded_cfg3_4ranks", mode=mode, frame0_vs_reference_fixture_mm=e0)
+    report(name, mode=mode, frame0_vs_reference_fixture_mm=e0)
     assert e0 < 1e-3
+
+
+@pytest.mark.parametrize("mode", ["alltoall", "allgather", "rank0"])
+def test_sharded_cfg3_four_ranks(mode, golden):
+    """BASELINE configs[3] on ONE GPU: the 12-camera rig sharded 3 cameras per rank over FOUR
+    emulated ranks, T = 4 frames.  `rank0` is the literal placement of configs[3] (heatmaps
+    all-gathered, 3D stage on rank 0)."""
+    _sharded_emulated("cfg3", 4, 4, mode, golden)
+
+
+@pytest.mark.parametrize("mode", ["alltoall", "allgather", "rank0"])
+def test_sharded_cfg5_eight_ranks(mode, golden):
+    """BASELINE configs[4] in its sharded form on ONE GPU: 16 cameras 1280x1024, 30 keypoints, 96^3 grid, 2 cameras
+    per rank over EIGHT emulated ranks, T = 8 frame sets (one 3D frame per rank in the frame-sharded modes; the
+    time-batch class whose P3 / P4 BiFPN nodes run in the row-streaming form)."""
+    _sharded_emulated("cfg5", 8, 8, mode, golden)
 
 
 def test_center3d_truncation_seed_sweep():

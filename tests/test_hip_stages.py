@@ -48,7 +48,7 @@ def test_efficienttrack(tag):
     assert torch.equal(a[safe], b[safe])
 
 
-@pytest.mark.parametrize("tag", ["j3_g16", "j23_g48", "j23_g64"])
+@pytest.mark.parametrize("tag", ["j3_g16", "j23_g48", "j23_g64", "j23_g72"])
 def test_v2v_and_tail(tag, golden):
     from jarvis_hybridnet_amd import _native as N
     from jarvis_hybridnet_amd import synthetic as S
@@ -86,7 +86,7 @@ def test_v2v_and_tail(tag, golden):
     assert (pts.cpu() - torch.from_numpy(g[tag + ".points"])).abs().max() < 1e-3
 
 
-@pytest.mark.parametrize("tag", ["tiny", "cfg2", "cfg3", "cfg5"])
+@pytest.mark.parametrize("tag", ["tiny", "cfg2", "cfg3", "cfg5", "ex72"])
 def test_reprojection(tag, golden):
     from types import SimpleNamespace as NS
     from jarvis_hybridnet_amd.hybridnet.repro_layer import ReprojectionLayer

@@ -54,6 +54,26 @@ def test_reprojection(golden, tag):
         check_summary(g, tag + ".vol", vol)
 
 
+def test_reprojection_ex72_every_index(golden):
+    """The geometry the reference ships (ROI 144 / spacing 2: a 72^3 grid, 4.5 M gather indices -- too many to
+    commit in full): the oracle's index field against the per-camera-plane hashes of the reference's."""
+    import json
+    from tests.util import index_plane_hashes
+    C, J, G, spacing = cases.REPRO_CASES["ex72"][:4]
+    inp = cases.repro_inputs("ex72")
+    vol, idx = O.reprojection_forward(inp["hm_pad"], inp["center3d"], inp["center_hm"],
+                                      inp["cam"], inp["intr"], inp["dist"],
+                                      G * spacing, spacing, chunk=5, return_idx=True)
+    here = os.path.dirname(os.path.abspath(__file__))
+    hashes = json.load(open(os.path.join(here, "golden", "reprojection_index_hashes.json")))["ex72"]
+    assert hashes["n"] == idx.numel() == 12 * 72 ** 3
+    if EXACT:
+        assert index_plane_hashes(idx) == hashes["planes"]
+        g = golden("reprojection")
+        check_summary(g, "ex72.idx", idx)
+        check_summary(g, "ex72.vol", vol)
+
+
 @pytest.mark.parametrize("tag", list(cases.V2V_CASES))
 def test_v2v_and_tail(golden, tag):
     J, G, wseed, xseed = cases.V2V_CASES[tag]
@@ -84,7 +104,7 @@ def test_geometry(golden, tag):
     assert (rec - p3d[0]).abs().max() < 5.0
 
 
-@pytest.mark.parametrize("tag", ["cfg2"])
+@pytest.mark.parametrize("tag", ["cfg2", "ex72"])
 def test_hybridnet(golden, tag):
     c = cases.HYBRID_CASES[tag]
     inp = cases.hybrid_inputs(tag)
@@ -99,17 +119,18 @@ def test_hybridnet(golden, tag):
     check_summary(g, tag + ".heatmaps_padded", hm, **TOL)
 
 
-@pytest.mark.parametrize("tag", ["cfg2", "cfg2_none", "cfg2_u8", "cfg5"])
+@pytest.mark.parametrize("tag", ["cfg2", "cfg2_none", "cfg2_u8", "cfg5", "ex72", "cfg3_medium"])
 def test_predictor(golden, tag):
     c = cases.PREDICTOR_CASES[tag]
     inp = cases.predictor_inputs(tag)
+    size = c.get("size", "small")
     inter = {}
     with torch.no_grad():
         pts, conf = O.predictor3d_forward(
             inp["sd_center"], inp["sd_hybrid"], inp["imgs"], inp["cam"], inp["intr"],
             inp["dist"], center_size=c["center_size"], bbox=c["bbox"],
             roi_cube_size=c["roi"], grid_spacing=c["spacing"], mean=S.MEAN, std=S.STD,
-            chunk=5, intermediates=inter)
+            chunk=5, center_model=size, kp_model=size, intermediates=inter)
     g = golden("predictor")
     assert int(g[tag + ".n_detect"]) == inter["n_detect"]
     if c.get("expect_none"):
