@@ -210,10 +210,13 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: run `python bench.py --gpus N` without a "
                          "launcher, or torch.distributed.run with --nproc-per-node equal to --gpus" %
                          (args.gpus, world))
-    have = torch.cuda.device_count()                       # (does not initialise the GPU)
-    if have < world:
+    # the bound is this NODE's share of the job (a multi-node launch has WORLD_SIZE > the node's GPUs; a rank
+    # restricted by *_VISIBLE_DEVICES sees fewer): every local rank needs its own visible device
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    have = torch.cuda.device_count()
+    if local_rank >= have:
         raise SystemExit("bench.py rank %d: --gpus %d needs %d GPUs on this node, %d visible" %
-                         (rank, world, world, have))
+                         (rank, world, local_world, have))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     sharded = world > 1 or args.force_sharded
@@ -497,37 +500,59 @@ def main():
             pred.forward(dev_u8, out)
         torch.cuda.synchronize()
         fps_pcie = T * 10 / (time.perf_counter() - t0)
-        # double-buffered: the copy of batch i+1 runs on its own stream under batch i
-        bufs = [dev_u8, torch.empty_like(dev_u8)]
-        copy_s, comp_s = torch.cuda.Stream(), torch.cuda.current_stream()
-        ready = [torch.cuda.Event(), torch.cuda.Event()]
-        freed = [torch.cuda.Event(), torch.cuda.Event()]
-        for e in freed:
-            e.record(comp_s)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        nb = 12
-        for i in range(nb + 1):
-            if i < nb:
-                with torch.cuda.stream(copy_s):
-                    copy_s.wait_event(freed[i % 2])
-                    bufs[i % 2].copy_(host, non_blocking=True)
-                    ready[i % 2].record(copy_s)
-            if i > 0:
-                j = (i - 1) % 2
-                comp_s.wait_event(ready[j])
-                pred.forward(bufs[j], out)
-                freed[j].record(comp_s)
-        torch.cuda.synchronize()
-        fps_overlap = T * nb / (time.perf_counter() - t0)
         line["uint8_ingest"] = {"frames_per_s_resident": fps_res,
                                 "frames_per_s_resident_%d_streams" % K: fps_res_k,
                                 "frames_per_s_incl_pcie_h2d_serial": fps_pcie,
-                                "frames_per_s_incl_pcie_h2d_overlapped": fps_overlap,
                                 "bytes_per_frame": int(host[0].numel()),
-                                "note": "one stream unless named; pinned host uint8 BGR -> HBM inside the timed region; "
-                                        "overlapped = copy of batch i+1 on a second HIP stream"}
-        del bufs, dev_u8, host
+                                "note": "one stream unless named; pinned host uint8 BGR -> HBM inside the timed region"}
+        # ---- the SHIPPED driver: predict3D_frames itself, fed a generator of numpy uint8 BGR frame sets as a
+        # decoder yields them, data3D.csv written to /dev/shm; pinned staging by a thread pool, upload on a copy
+        # stream, K time batches in flight (jarvis_hybridnet_amd/prediction/_ingest.py).  PCIe-inclusive: never `value`.
+        try:
+            import shutil
+            from types import SimpleNamespace as NS
+            from jarvis_hybridnet_amd.prediction.jarvis3D import JarvisPredictor3D
+            from jarvis_hybridnet_amd.prediction.predict3D import frame_row, predict3D_frames
+            from jarvis_hybridnet_amd.prediction._ingest import release_ingest_buffers
+            cfg_ns = NS(PARENT_DIR="/nonexistent", PROJECT_NAME="bench",
+                        DATASET=NS(DATASET_ROOT_DIR="x", MEAN=S.MEAN, STD=S.STD),
+                        CENTERDETECT=NS(MODEL_SIZE=size, NUM_JOINTS=1, IMAGE_SIZE=c["center"]),
+                        KEYPOINTDETECT=NS(MODEL_SIZE=size, NUM_JOINTS=c["J"], BOUNDING_BOX_SIZE=c["bbox"]),
+                        HYBRIDNET=NS(NUM_CAMERAS=c["C"], ROI_CUBE_SIZE=c["roi"], GRID_SPACING=c["spacing"]))
+            jp = JarvisPredictor3D(cfg_ns, sd_c, sd_h)
+            sets = [u8[i].numpy() for i in range(len(distinct))]
+
+            def decoded(n):
+                for i in range(n):
+                    yield sets[i % len(sets)]
+            Kd = max(1, args.streams)
+            odir = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", "jh_bench_driver_%d" % os.getpid())
+            predict3D_frames(jp, decoded(T * Kd), *calib_dev, cfg_ns, odir, time_batch=T, streams=Kd)   # plans + pinning
+            nd = T * Kd * 8
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            got = predict3D_frames(jp, decoded(nd), *calib_dev, cfg_ns, odir, time_batch=T, streams=Kd)
+            ddt = time.perf_counter() - t0
+            import csv as _csv
+            rows = list(_csv.reader(open(os.path.join(odir, "data3D.csv"))))
+            pred.forward(dev_u8, out)                            # the resident path on the same bytes
+            torch.cuda.synchronize()
+            rp, rc, rv = [t.cpu() for t in out]
+            same = len(rows) == nd and all(
+                rows[t] == [str(v) for v in frame_row(rp[t] if int(rv[t]) else None, rc[t] if int(rv[t]) else None, c["J"])]
+                for t in range(min(T, nd)))
+            line["driver"] = {"frames_per_s": got / ddt, "frames": got, "time_batch": T, "streams": Kd,
+                              "rows_equal_resident_forward": bool(same),
+                              "pipeline_slots": next(iter(jp._ingest_cache.values())).slots,
+                              "note": "predict3D_frames() end to end: generator of numpy uint8 BGR frame sets -> pinned "
+                                      "staging (thread pool) -> H2D on a copy stream -> MultiStreamPredictor -> data3D.csv "
+                                      "on /dev/shm; PCIe bound = bytes_per_frame / host-to-device bandwidth"}
+            release_ingest_buffers(jp)
+            shutil.rmtree(odir, ignore_errors=True)
+            del jp
+        except Exception as e:                                   # noqa: BLE001 -- a side leg never loses the headline
+            line["driver"] = {"error": repr(e)}
+        del dev_u8, host
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # ---- CPU baseline: the oracle (port of the reference) on the host cores,

@@ -183,7 +183,10 @@ class MultiStreamPredictor:
                     t.record_stream(s)
         self._calib = key
 
-    def forward(self, frames, out=None):
+    def forward(self, frames, out=None, then=None):
+        """`then(outputs)`, when given, runs inside the batch's stream context right behind the forward and
+        before its event is recorded (the drivers enqueue the device->host copy of the results there); its
+        return value replaces the outputs."""
         i = self._next
         self._next = (i + 1) % len(self.preds)
         s = self.streams[i]
@@ -197,6 +200,8 @@ class MultiStreamPredictor:
             t.record_stream(s)
         with torch.cuda.stream(s):
             res = self.preds[i].forward(frames, out)
+            if then is not None:
+                res = then(res)
             ev = torch.cuda.Event(enable_timing=self.timing)
             ev.record(s)
         self.events[i] = ev

@@ -257,16 +257,22 @@ int launch_conv3d_bf16x3(const ConvWeights& w, const Act& x, const Act& y, doubl
   a.N = x.N; a.D = x.D; a.H = x.H; a.W = x.W; a.cin_p = x.Cp; a.cout_p = y.Cp; a.cout_p16 = w.cout_p16;
   a.nchunk = (x.Cp + 15) / 16; a.ncbt = w.cout_p16 / 16;
   a.tiles_x = (x.W + TX - 1) / TX; a.tiles_y = (x.H + TY - 1) / TY; a.tiles_z = (x.D + TZ - 1) / TZ;
-  switch (a.ncbt) {
-    case 1: return launch_b3<1>(a, 1, s);
-    case 2: return launch_b3<2>(a, 1, s);
-    case 3: return launch_b3<3>(a, 1, s);
-    case 4: return launch_b3<4>(a, 1, s);
-    case 6: return launch_b3<3>(a, 2, s);       // (6 blocks in one workgroup: 264 registers, one wave per SIMD)
-    case 8: return launch_b3<4>(a, 2, s);
-    case 12: return launch_b3<4>(a, 3, s);
-    default: JH_REQUIRE(false, "bf16x3 conv: unsupported output channel count");
+  // column blocks per workgroup x groups of workgroups (blockIdx.z).  Any channel count is served: a group that
+  // reaches past the last column block reads other (or out-of-range = zero) weights into accumulators whose
+  // channels lie beyond cout_p, which the epilogue neither stores nor counts.  3 or 4 blocks per workgroup,
+  // whichever pads less (4 on a tie): 5 -> 3 x 2, 6 -> 3 x 2, 7 -> 4 x 2, 8 -> 4 x 2, 9 -> 3 x 3, 12 -> 4 x 3, ...
+  // (6 blocks in one workgroup would take 264 registers: one wave per SIMD)
+  if (a.ncbt <= 4) {
+    switch (a.ncbt) {
+      case 1: return launch_b3<1>(a, 1, s);
+      case 2: return launch_b3<2>(a, 1, s);
+      case 3: return launch_b3<3>(a, 1, s);
+      default: return launch_b3<4>(a, 1, s);
+    }
   }
+  const int g4 = (a.ncbt + 3) / 4, g3 = (a.ncbt + 2) / 3;
+  if (4 * g4 <= 3 * g3) return launch_b3<4>(a, g4, s);
+  return launch_b3<3>(a, g3, s);
   return 0;
 }
 

@@ -28,6 +28,7 @@
 // (voxel q / Q, channel quad q % Q): loads are 16-byte, output stores are
 // fully coalesced 16-byte writes of 64*Jp*4 contiguous bytes per wave.
 #include <algorithm>
+#include <atomic>
 #include "jh_common.h"
 
 namespace jh {
@@ -594,11 +595,15 @@ __global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
 template <int Q, int CI, int NT>
 static int launch_cube(const CubeArgs& a, int T, hipStream_t s) {
   auto kern = repro_cube_kernel<Q, CI, NT>;
-  static bool big = false;
-  if (!big) {
+  // the attribute belongs to the CURRENT device: one flag per device (a process may drive several GPUs, and
+  // two host threads may build predictors at the same time -- setting it twice is harmless)
+  static std::atomic<bool> big[64];
+  int devid = 0;
+  JH_CHECK_HIP(hipGetDevice(&devid));
+  if (devid < 0 || devid >= 64 || !big[devid].load(std::memory_order_acquire)) {
     JH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    big = true;
+    if (devid >= 0 && devid < 64) big[devid].store(true, std::memory_order_release);
   }
   const int cubes = (a.G / CI) * (a.G / kCubeJ) * (a.G / kCubeK);
   hipLaunchKernelGGL(kern, dim3(cubes, T), dim3(NT), (size_t)kCubePatchOff(CI) + 2 * a.patch_bytes, s, a);

@@ -54,20 +54,28 @@ def frame_row(points2D, confidences, num_joints):
 
 
 def predict2D_frames(predictor, frames, cfg, output_dir, params=None, time_batch=1,
-                     csv_name="data2D.csv"):
+                     csv_name="data2D.csv", frame_spec=None):
     """Run `predictor` (JarvisPredictor2D) over an iterable of frames -- (H,W,3) uint8 BGR arrays
     / tensors exactly as cv2 delivers them, or (3,H,W) fp32 RGB -- and write `csv_name`
     (+ info.yaml when `params` is given).  Returns the number of frames.
+
+    Frames are staged in pinned memory by a thread pool as the iterator yields them and uploaded per
+    time batch on a copy stream while the previous batch is computed (`_ingest.FramePipeline`, the
+    same pipeline as predict3D_frames; an item may be a callable `fill(dst)` decoding in place, with
+    `frame_spec=((H,W,3), torch.uint8)`).
 
     time_batch > 1 groups that many consecutive frames into one launch sequence
     (`forward_batch`); rows are written in frame order and are the same as with
     time_batch = 1.  A short last group is padded with its last frame and the padding rows
     are dropped."""
+    from ._ingest import host_outputs, pipeline_for
+    from .predict3D import _as_host
     os.makedirs(output_dir, exist_ok=True)
     if params is not None:
         params.output_dir = output_dir
         create_info_file(params)
     J = cfg.KEYPOINTDETECT.NUM_JOINTS
+    time_batch = max(1, int(time_batch))
     n = 0
     with open(os.path.join(output_dir, csv_name), "w", newline="") as f:
         writer = csv.writer(f, delimiter=",", quotechar='"', quoting=csv.QUOTE_MINIMAL)
@@ -75,40 +83,40 @@ def predict2D_frames(predictor, frames, cfg, output_dir, params=None, time_batch
         if len(names) == J:
             create_header(writer, cfg)
 
-        def flush(group):
-            real = len(group)
-            x = torch.stack(group + [group[-1]] * (time_batch - real)).cuda()
-            pts, conf, valid = predictor.forward_batch(x)
-            pts, conf, valid = pts.long().cpu(), conf.cpu(), valid.cpu()
+        def emit(outs, real):
+            pts, conf, valid = outs
+            pts = pts.long()
             for t in range(real):
                 ok = int(valid[t]) != 0
                 writer.writerow(frame_row(pts[t] if ok else None, conf[t] if ok else None, J))
-            return real
 
-        group = []
+        ring = {}                                               # pinned host copies of the outputs, per slot
+
+        def submit(x, slot):
+            # the reference driver's own conversion of uint8 frames (predict2D.py:93-94) is what the
+            # uint8 entry point fuses into the resize / crop kernels
+            res = predictor.forward_batch(x)
+            ev = None
+            if x.is_cuda:
+                res = host_outputs(ring, slot, res)
+                ev = torch.cuda.Event()
+                ev.record()
+            return res, ev
+
+        pipe, key = None, None
         for frame in frames:
-            x = torch.as_tensor(frame)
-            if time_batch > 1:
-                if group and (x.dtype != group[0].dtype or x.shape != group[0].shape):
-                    n += flush(group)
-                    group = []
-                group.append(x)
-                if len(group) == time_batch:
-                    n += flush(group)
-                    group = []
-                continue
-            if x.dtype == torch.uint8:
-                # the reference driver's own conversion (predict2D.py:93-94) is what the uint8
-                # entry point fuses into the resize / crop kernels
-                pts, conf, valid = predictor.forward_batch(x.unsqueeze(0).cuda())
-                ok = int(valid[0].item()) != 0
-                pts, conf = (pts[0].long(), conf[0]) if ok else (None, None)
+            if not callable(frame):
+                frame = frame if torch.is_tensor(frame) and frame.is_cuda else _as_host(frame)
+                k = (frame.dtype, tuple(frame.shape), torch.is_tensor(frame))
             else:
-                pts, conf = predictor(x.unsqueeze(0).cuda())
-            writer.writerow(frame_row(pts, conf, J))
-            n += 1
-        if group:
-            n += flush(group)
+                k = key if key is not None else ("fill",)
+            if pipe is None or k != key:
+                if pipe is not None:
+                    n += pipe.finish()
+                pipe, key = pipeline_for(predictor, frame, time_batch, 1, submit, emit, frame_spec), k
+            pipe.push(frame)
+        if pipe is not None:
+            n += pipe.finish()
     return n
 
 

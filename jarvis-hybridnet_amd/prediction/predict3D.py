@@ -64,25 +64,36 @@ def frame_row(points3D, confidences, num_joints):
 
 
 def predict3D_frames(predictor, frame_sets, cameraMatrices, intrinsicMatrices,
-                     distortionCoefficients, cfg, output_dir, params=None, time_batch=1, streams=1):
+                     distortionCoefficients, cfg, output_dir, params=None, time_batch=1, streams=1,
+                     frame_spec=None):
     """Run `predictor` over an iterable of multi-view frame sets -- (C,H,W,3) uint8 BGR
     arrays / tensors exactly as cv2 delivers them, or (C,3,H,W) fp32 RGB -- and write
     data3D.csv (+ info.yaml when `params` is given).  Returns the number of frames.
 
+    Ingest is overlapped as in the reference driver, which reads the next frame set with 12 threads
+    and uploads it while nothing else waits (predict3D.py:72-85): frame sets are copied into pinned
+    staging buffers by a thread pool as the iterator yields them, uploaded per time batch on a copy
+    stream and consumed by `streams` predictors on their own HIP streams (`_ingest.FramePipeline`;
+    no `torch.stack`, no pageable host->device copy).  An item of `frame_sets` may also be a callable
+    `fill(dst)` that decodes one frame set straight into the pinned numpy view `dst` (the reference's
+    `read_images(cap, slice, imgs_orig)` pattern; pass `frame_spec=((C,H,W,3), torch.uint8)` then).
+
     time_batch > 1 groups that many consecutive frame sets into one launch sequence
-    (`forward_batch`, the throughput form the bench measures); rows are written in frame
+    (the throughput form the bench measures); rows are written in frame
     order and are the same as with time_batch = 1 -- bit for bit up to time_batch 7, to about
     1e-5 mm from 8 on (the high-resolution BiFPN nodes then run in their row-streaming form,
     DESIGN.md section 1; a row does not depend on its position in the group or on `streams`).
     A short last group is padded with its last frame set and the padding rows are dropped.
-    streams > 1 (with time_batch > 1) keeps that many groups in flight on as many HIP streams;
+    streams > 1 keeps that many groups in flight on as many HIP streams;
     rows still come out in frame order and are identical to the streams = 1 run."""
+    from ._ingest import host_outputs, pipeline_for
     os.makedirs(output_dir, exist_ok=True)
     if params is not None:
         params.output_dir = output_dir
         create_info_file(params)
     J = cfg.KEYPOINTDETECT.NUM_JOINTS
     calib = (cameraMatrices, intrinsicMatrices, distortionCoefficients)
+    time_batch, streams = max(1, int(time_batch)), max(1, int(streams))
     n = 0
     with open(os.path.join(output_dir, "data3D.csv"), "w", newline="") as f:
         writer = csv.writer(f, delimiter=",", quotechar='"', quoting=csv.QUOTE_MINIMAL)
@@ -90,56 +101,49 @@ def predict3D_frames(predictor, frame_sets, cameraMatrices, intrinsicMatrices,
         if len(names) == J:
             create_header(writer, cfg)
 
-        inflight = []                               # (outputs, event, real) of submitted groups
-
-        def drain(keep):
-            while len(inflight) > keep:
-                (pts, conf, valid), ev, real = inflight.pop(0)
-                ev.synchronize()
-                pts, conf, valid = pts.cpu(), conf.cpu(), valid.cpu()
-                for t in range(real):
-                    ok = int(valid[t]) != 0
-                    writer.writerow(frame_row(pts[t] if ok else None, conf[t] if ok else None, J))
-
-        def flush(group):
-            real = len(group)
-            group = group + [group[-1]] * (time_batch - real)
-            x = torch.stack(group).cuda()
-            if streams > 1:
-                h, w = (x.shape[2], x.shape[3]) if x.dtype == torch.uint8 else (x.shape[3], x.shape[4])
-                msp = predictor.native_streams(h, w, time_batch, streams)
-                msp.set_calibration(*calib)
-                drain(streams - 1)                  # the stream about to be reused must be idle
-                res = msp.forward(x)
-                inflight.append((res, msp.last_event, real))
-                return real
-            pts, conf, valid = predictor.forward_batch(x, *calib)
-            pts, conf, valid = pts.cpu(), conf.cpu(), valid.cpu()
+        def emit(outs, real):
+            pts, conf, valid = outs
             for t in range(real):
                 ok = int(valid[t]) != 0
                 writer.writerow(frame_row(pts[t] if ok else None, conf[t] if ok else None, J))
-            return real
 
-        group = []
+        ring = {}                                               # pinned host copies of the outputs, per slot
+
+        def submit(x, slot):
+            if hasattr(predictor, "native_streams"):
+                h, w = (x.shape[2], x.shape[3]) if x.dtype == torch.uint8 else (x.shape[3], x.shape[4])
+                msp = predictor.native_streams(h, w, time_batch, streams)
+                msp.set_calibration(*calib)
+                # results leave for pinned host memory on the forward's own stream (behind it, before its event)
+                res = msp.forward(x, then=lambda outs: host_outputs(ring, slot, outs))
+                return res, msp.last_event
+            res = predictor.forward_batch(x, *calib)           # any object with the batch interface
+            ev = None
+            if x.is_cuda:
+                res = host_outputs(ring, slot, res)
+                ev = torch.cuda.Event()
+                ev.record()
+            return res, ev
+
+        pipe, key = None, None
         for frames in frame_sets:
-            x = torch.as_tensor(frames)
-            if time_batch > 1:
-                if group and (x.dtype != group[0].dtype or x.shape != group[0].shape):
-                    n += flush(group)
-                    drain(0)
-                    group = []
-                group.append(x)
-                if len(group) == time_batch:
-                    n += flush(group)
-                    group = []
-                continue
-            if x.dtype == torch.uint8:
-                pts, conf = predictor.forward_uint8(x.cuda(), *calib)
+            if not callable(frames):
+                frames = frames if torch.is_tensor(frames) and frames.is_cuda else _as_host(frames)
+                k = (frames.dtype, tuple(frames.shape), torch.is_tensor(frames))
             else:
-                pts, conf = predictor(x.cuda(), *calib)
-            writer.writerow(frame_row(pts, conf, J))
-            n += 1
-        if group:
-            n += flush(group)
-        drain(0)
+                k = key if key is not None else ("fill",)
+            if pipe is None or k != key:                        # first frame set, or a new frame format
+                if pipe is not None:
+                    n += pipe.finish()
+                pipe, key = pipeline_for(predictor, frames, time_batch, streams, submit, emit, frame_spec), k
+            pipe.push(frames)
+        if pipe is not None:
+            n += pipe.finish()
     return n
+
+
+def _as_host(frames):
+    """numpy view of a decoded frame set (numpy array or CPU tensor), C-contiguous."""
+    import numpy as np
+    a = frames.detach().numpy() if torch.is_tensor(frames) else np.asarray(frames)
+    return a if a.flags.c_contiguous else np.ascontiguousarray(a)

@@ -23,11 +23,14 @@ def bf16x3():
 
 @pytest.mark.parametrize("cin,cout,D,H,W,norm_act", [(46, 46, 16, 16, 16, 1), (92, 92, 8, 12, 20, 1),
                                                      (6, 23, 5, 9, 11, -1), (60, 60, 12, 12, 48, 1),
-                                                     (120, 120, 6, 10, 14, 1), (46, 46, 32, 32, 32, -1)])
+                                                     (120, 120, 6, 10, 14, 1), (46, 46, 32, 32, 32, -1),
+                                                     (80, 80, 6, 8, 18, 1), (100, 100, 5, 6, 16, 1),
+                                                     (72, 72, 4, 8, 16, -1), (136, 136, 4, 4, 16, 1)])
 def test_conv3d_bf16x3_vs_torch(cin, cout, D, H, W, norm_act, bf16x3):
     """One 3x3x3 stride-1 convolution (+ the fused InstanceNorm + ReLU of the network) against torch
-    fp32 on the CPU, incl. volumes that are not multiples of the 4 x 4 x 16 tile and channel counts
-    that need two column-block groups."""
+    fp32 on the CPU, incl. volumes that are not multiples of the 4 x 4 x 16 tile, channel counts
+    that need two column-block groups, and counts whose 16-channel blocks do not fill the groups (80 and 72 -> 5
+    blocks as 3 x 2, 100 -> 7 as 4 x 2, 136 -> 9 as 3 x 3: V2V has 2J and 4J channels, any J must build)."""
     from tests.test_hip_ops import _conv
     g = torch.Generator().manual_seed(cin + D)
     x = torch.randn(2, cin, D, H, W, generator=g)
@@ -120,6 +123,26 @@ def test_v2v_bf16x3(tag, golden, bf16x3):
     eg = float((pts.cpu() - torch.from_numpy(golden("v2v")[tag + ".points"])).abs().max())
     report("v2v_bf16x3", tag=tag, rel=e, points_mm=ep, conf=ec, points_mm_vs_fixture=eg)
     assert e < 2e-4 and ep < 1e-3 and eg < 1e-3 and ec < 1e-4
+
+
+@pytest.mark.parametrize("J", [17, 20, 25])
+def test_v2v_bf16x3_any_joint_count(J, bf16x3):
+    """Joint counts whose 4J channels are 5 or 7 sixteen-channel blocks (J = 17, 20 -> 68, 80; J = 25 -> 100): the
+    split-bf16 3x3x3 kernel pads the last column-block group instead of refusing the layer."""
+    from jarvis_hybridnet_amd import synthetic as S
+    from jarvis_hybridnet_amd.hybridnet.v2vnet import V2VNet
+    from oracle import hybridnet_oracle as O
+    sd = S.v2v_weights(J, 90 + J)
+    x = cases.v2v_input(J, 24, 91 + J)
+    with torch.no_grad():
+        ref = O.v2v_forward(sd, x)
+    net = V2VNet(J, J)
+    net.load_state_dict(sd, strict=True)
+    out = net(cuda(x))
+    torch.cuda.synchronize()
+    e = rel_err(out, ref)
+    report("v2v_bf16x3_any_J", J=J, rel=e)
+    assert e < 2e-4
 
 
 @pytest.mark.parametrize("tag", ["cfg2", "cfg3", "cfg5"])

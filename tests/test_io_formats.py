@@ -176,6 +176,60 @@ def test_predict2D_frames_driver(golden, tmp_path):
     assert os.path.isfile(tmp_path / "multi" / "info.yaml")
 
 
+def test_predict3D_frames_pipeline_host_logic(tmp_path):
+    """predict3D_frames over the staged ingest pipeline with a stub predictor (CPU: plain host buffers, no
+    streams): rows in frame order for any time_batch / streams, short last batch padded and its padding rows
+    dropped, 'NaN' rows for undetected frame sets, a frame-format change mid-stream, in-place `fill(dst)`
+    callables, and the staging buffers re-used by a second call."""
+    import numpy as np
+    from jarvis_hybridnet_amd.prediction import predict3D as P
+    from jarvis_hybridnet_amd.prediction._ingest import release_ingest_buffers
+    J, C = 3, 2
+    cfg = NS(KEYPOINT_NAMES=["a", "b", "c"], KEYPOINTDETECT=NS(NUM_JOINTS=J))
+
+    class Stub:
+        """points = frame id + joint index; frame sets whose first byte is 255 are `not detected`"""
+        calls = 0
+
+        def forward_batch(self, x, *calib):
+            Stub.calls += 1
+            ids = x.reshape(x.shape[0], -1)[:, 0].float()
+            pts = ids[:, None, None] + torch.arange(J).float()[None, :, None] + torch.zeros(1, 1, 3)
+            return pts, torch.full((x.shape[0], J), 0.5), (ids != 255).int()
+
+    def sets(n, shape=(C, 4, 6, 3), dtype=np.uint8):
+        return [np.full(shape, 255 if i == 2 else i, dtype=dtype) for i in range(n)]
+
+    def rows(path):
+        return list(csv.reader(open(os.path.join(path, "data3D.csv"))))[2:]
+    expect = None
+    for tb, st in ((1, 1), (2, 1), (3, 2), (4, 3), (16, 1)):
+        pred = Stub()
+        out = str(tmp_path / ("tb%d_%d" % (tb, st)))
+        assert P.predict3D_frames(pred, iter(sets(7)), None, None, None, cfg, out, time_batch=tb, streams=st) == 7
+        got = rows(out)
+        assert len(got) == 7 and got[2] == ["NaN"] * (4 * J)
+        assert [float(r[0]) for i, r in enumerate(got) if i != 2] == [0.0, 1.0, 3.0, 4.0, 5.0, 6.0]
+        expect = expect or got
+        assert got == expect
+    # a new frame format mid-stream flushes the batch under way first; fp32 (C,3,H,W) after uint8 (C,H,W,3)
+    pred = Stub()
+    mixed = sets(3) + [np.full((C, 3, 4, 6), 7.0, dtype=np.float32)] + sets(2)
+    out = str(tmp_path / "mixed")
+    assert P.predict3D_frames(pred, mixed, None, None, None, cfg, out, time_batch=2) == 6
+    assert [r[0] for r in rows(out)] == ["0.0", "1.0", "NaN", "7.0", "0.0", "1.0"]
+    # decode-in-place callables (the reference's read_images(cap, slice, imgs_orig) pattern)
+    fills = [(lambda dst, i=i: dst.fill(i)) for i in (4, 5, 6)]
+    out = str(tmp_path / "fill")
+    calls = Stub.calls
+    assert P.predict3D_frames(pred, fills, None, None, None, cfg, out, time_batch=2,
+                              frame_spec=((C, 4, 6, 3), torch.uint8)) == 3
+    assert [r[0] for r in rows(out)] == ["4.0", "5.0", "6.0"] and Stub.calls == calls + 2
+    assert len(pred._ingest_cache) == 2                      # uint8 and fp32 staging, re-used by the fill run
+    release_ingest_buffers(pred)
+    assert not hasattr(pred, "_ingest_cache")
+
+
 def test_info_yaml_scalars_round_trip(tmp_path):
     """info.yaml stays valid YAML for any recording path (': ', '#', quotes, leading '-', strings
     that look like numbers / booleans / null): a YAML loader returns what was written."""
