@@ -610,17 +610,15 @@ def main():
         except Exception as e:
             line["invalid_frame_check"] = {"error": repr(e)[:200]}
 
-    if rank == 0 and not sharded and not args.no_reduced_precision and N.get_precision() == "f32":
+    if rank == 0 and not sharded and not args.no_reduced_precision and pred.precision == "f32":
         # ---- separately labelled reduced-precision line (BASELINE configs[1] is worded "bf16"; the
         # reference's own fast path is half precision, jarvis3D.py:93,107,122): V2V's 3x3x3 convolutions
         # on the bf16 matrix cores with split operands (csrc/conv3d_bf16x3.hip), everything else as in
         # the headline.  Same frames, same method, half the steps; never the headline `value`.
         try:
-            N.set_precision("bf16x3")
-            try:
-                rp = MultiStreamPredictor(lambda: NativePredictor(sd_c, sd_h, **common), streams=K)
-            finally:
-                N.set_precision("f32")
+            # (precision is a property of the predictor, jh_predictor_config.precision: these coexist with the
+            # fp32 predictors of the headline in this process)
+            rp = MultiStreamPredictor(lambda: NativePredictor(sd_c, sd_h, precision="bf16x3", **common), streams=K)
             rp.set_calibration(*calib_dev)
             routs = [(torch.empty((T, c["J"], 3), device=dev), torch.empty((T, c["J"]), device=dev),
                       torch.empty((T,), device=dev, dtype=torch.int32)) for _ in range(K)]

@@ -32,12 +32,16 @@
 extern "C" {
 #endif
 
-#define JH_ABI_VERSION 3
+#define JH_ABI_VERSION 4
 
 const char* jh_last_error(void);
 int jh_abi_version(void);
 
-/* ---- precision mode of the networks / predictors CREATED from now on (process-wide switch).
+/* ---- precision mode.  A predictor carries its own (jh_predictor_config.precision, ABI v4): two
+ * predictors of different precision coexist in one process and do not depend on call order.
+ * jh_set_precision() only sets the process-wide DEFAULT: what the stand-alone networks
+ * (jh_efftrack_create, jh_v2v_create, jh_op_*) CREATED from now on use, and what a predictor
+ * configured with JH_PRECISION_DEFAULT picks up when it is created.
  * JH_PRECISION_F32 (default): fp32 products and accumulation everywhere, the mode every parity
  * figure of this library is quoted in.  JH_PRECISION_BF16X3: the 3x3x3 stride-1 convolutions of
  * V2V, its stride-2 front convolution and the keypoint head's ConvTranspose2d run on the bf16 matrix
@@ -48,6 +52,7 @@ int jh_abi_version(void);
  * JH_PRECISION_BF16X3_WIDE additionally splits the dense k x k convolutions of the EfficientNet trunk
  * (experimental: up to 7.6e-4 mm on the fixture cases, no margin under the 1e-3 mm bar).
  * Environment JH_PRECISION=bf16x3 / bf16x3_wide sets the initial mode. */
+#define JH_PRECISION_DEFAULT (-1) /* jh_predictor_config.precision only: follow jh_set_precision / JH_PRECISION */
 #define JH_PRECISION_F32 0
 #define JH_PRECISION_BF16X3 1
 #define JH_PRECISION_BF16X3_WIDE 2
@@ -140,6 +145,9 @@ typedef struct {
   int32_t time_batch_3d;      /* frames per stage_3d call (<= T; 0 means T) */
   int32_t cam_lo, cam_n;
   float mean[3], std[3];      /* DATASET.MEAN / DATASET.STD */
+  int32_t precision;          /* JH_PRECISION_F32 (0: what a zero-initialised struct gets), _BF16X3, _BF16X3_WIDE,
+                               * or JH_PRECISION_DEFAULT = the process default at creation time.  The mode that
+                               * stands where the reference has trt_mode != 'off' (jarvis3D.py:42-46,93,107,122) */
 } jh_predictor_config;
 
 /* center_params may be NULL (HybridNetBackbone-only use). */
@@ -148,6 +156,7 @@ int jh_predictor_create(const jh_params* center_params, const jh_params* hybrid_
 void jh_predictor_destroy(jh_predictor* pr);
 int64_t jh_predictor_launches(const jh_predictor* pr);
 int64_t jh_predictor_device_bytes(const jh_predictor* pr);
+int jh_predictor_precision(const jh_predictor* pr);    /* the resolved mode (never JH_PRECISION_DEFAULT) */
 
 /* calibration of all cameras (device pointers, copied). */
 int jh_predictor_set_calibration(jh_predictor* pr, const float* cam_dev, const float* intr_dev,

@@ -25,12 +25,13 @@ class PredictorConfig(ctypes.Structure):
                 ("img_h", ctypes.c_int32), ("img_w", ctypes.c_int32),
                 ("time_batch", ctypes.c_int32), ("time_batch_3d", ctypes.c_int32),
                 ("cam_lo", ctypes.c_int32),
-                ("cam_n", ctypes.c_int32), ("mean", c_float * 3), ("std", c_float * 3)]
+                ("cam_n", ctypes.c_int32), ("mean", c_float * 3), ("std", c_float * 3),
+                ("precision", ctypes.c_int32)]
 
 
-ABI_VERSION = 3                      # JH_ABI_VERSION of include/jarvis_hip.h
+ABI_VERSION = 4                      # JH_ABI_VERSION of include/jarvis_hip.h
 # sizeof(jh_predictor_config): statically asserted on the C side (tests/abi_smoke.c) and here
-assert ctypes.sizeof(PredictorConfig) == 80
+assert ctypes.sizeof(PredictorConfig) == 84
 
 _WORKSPACES = {}
 
@@ -83,6 +84,7 @@ _SIGS = {
     "jh_predictor_graph_replay": (c_int, [c_void_p]),
     "jh_predictor_launches": (c_int64, [c_void_p]),
     "jh_predictor_device_bytes": (c_int64, [c_void_p]),
+    "jh_predictor_precision": (c_int, [c_void_p]),
     "jh_predictor_set_calibration": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "jh_predictor_stage_center": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "jh_predictor_stage_keypoints": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -142,10 +144,22 @@ def lib():
 
 
 PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x3_wide": 2}
+PRECISION_DEFAULT = -1               # jh_predictor_config.precision: follow set_precision() / JH_PRECISION
+
+
+def precision_id(mode):
+    """jh_predictor_config.precision for a mode name; None = the process default (set_precision)."""
+    if mode is None:
+        return PRECISION_DEFAULT
+    if mode not in PRECISIONS:
+        raise ValueError("precision must be one of %s or None, got %r" % (sorted(PRECISIONS), mode))
+    return PRECISIONS[mode]
 
 
 def set_precision(mode):
-    """Precision mode of the native networks / predictors created from now on: "f32" (default, the
+    """Process-wide DEFAULT precision: the mode of the stand-alone networks created from now on and of
+    predictors built with precision=None; a predictor built with an explicit `precision=` ignores it.
+    "f32" (default, the
     parity mode), "bf16x3" (V2V's 3x3x3 convolutions and the keypoint head's ConvTranspose2d on the bf16
     matrix cores with split operands; a separately labelled reduced-precision mode) or "bf16x3_wide"
     (experimental: the trunk's dense 2D convolutions too).  Returns the previous mode."""

@@ -13,12 +13,15 @@ class NativePredictor:
 
     def __init__(self, center_state, hybrid_state, *, num_cameras, num_joints, center_size, bbox,
                  roi_cube_size, grid_spacing, img_h, img_w, mean, std, center_model="small",
-                 kp_model="small", time_batch=1, time_batch_3d=0, cam_lo=0, cam_n=None):
+                 kp_model="small", time_batch=1, time_batch_3d=0, cam_lo=0, cam_n=None, precision=None):
+        """precision: "f32" | "bf16x3" | "bf16x3_wide" for THIS predictor, or None = the process default
+        (`_native.set_precision`, environment JH_PRECISION) at creation time."""
         cam_n = num_cameras if cam_n is None else cam_n
         cfg = N.PredictorConfig(
             num_cameras, num_joints, center_size, bbox, float(roi_cube_size), float(grid_spacing),
             arch.SIZE_IDS[center_model], arch.SIZE_IDS[kp_model], img_h, img_w, time_batch,
-            time_batch_3d, cam_lo, cam_n, (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std))
+            time_batch_3d, cam_lo, cam_n, (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std),
+            N.precision_id(precision))
         self.cfg = cfg
         self.T, self.C, self.Cloc, self.J = time_batch, num_cameras, cam_n, num_joints
         self.T3 = time_batch_3d if time_batch_3d > 0 else time_batch
@@ -29,6 +32,7 @@ class NativePredictor:
         ph = N.Params(hybrid_state)
         N.check(N.lib().jh_predictor_create(pc.handle if pc else None, ph.handle,
                                             ctypes.byref(cfg), ctypes.byref(self.handle)))
+        self.precision = {v: k for k, v in N.PRECISIONS.items()}[N.lib().jh_predictor_precision(self.handle)]
         self.launches = N.lib().jh_predictor_launches(self.handle)
         self.device_bytes = N.lib().jh_predictor_device_bytes(self.handle)
 

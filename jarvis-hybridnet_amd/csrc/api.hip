@@ -340,16 +340,24 @@ int jh_predictor_create(const jh_params* center_params, const jh_params* hybrid_
   const int N = pr->T * pr->Cloc;
   // (form of the BiFPN nodes: by the time batch alone, see EffTrackPlan::node_rows)
   const int node_rows = pr->T >= 8 ? 1 : 0;
+  // precision: the predictor's own setting; JH_PRECISION_DEFAULT follows the process-wide default
+  JH_REQUIRE(cfg->precision >= JH_PRECISION_DEFAULT && cfg->precision <= JH_PRECISION_BF16X3_WIDE,
+             "jh_predictor_config.precision: unknown mode");
+  const int precision = cfg->precision == JH_PRECISION_DEFAULT ? precision_mode() : cfg->precision;
+  pr->cfg.precision = precision;
   if (center_params) {
     pr->center.reset(new EffTrackPlan());
+    pr->center->precision = precision;
     pr->center->node_rows = node_rows;
     if (pr->center->build(center_params->map, "", cfg->center_model, 1, N, cfg->center_size,
                           cfg->center_size)) return 1;
   }
   pr->kp.reset(new EffTrackPlan());
+  pr->kp->precision = precision;
   pr->kp->node_rows = node_rows;
   if (pr->kp->build(hybrid_params->map, "effTrack.", cfg->kp_model, pr->J, N, pr->B, pr->B)) return 1;
   pr->v2v.reset(new V2VPlan());
+  pr->v2v->precision = precision;
   if (pr->v2v->build(hybrid_params->map, "v2vNet.", pr->J, pr->T3, pr->G)) return 1;
   auto& m = pr->mem;
   const int T = pr->T, C = pr->C;
@@ -402,6 +410,8 @@ int64_t jh_predictor_launches(const jh_predictor* pr) {
   return (int64_t)((pr->center ? pr->center->launches() : 0) + pr->kp->launches() +
                    pr->v2v->launches());
 }
+int jh_predictor_precision(const jh_predictor* pr) { return pr ? pr->cfg.precision : -1; }
+
 int64_t jh_predictor_device_bytes(const jh_predictor* pr) {
   return (int64_t)((pr->center ? pr->center->device_bytes() : 0) + pr->kp->device_bytes() +
                    pr->v2v->device_bytes());
@@ -655,10 +665,16 @@ int jh_predictor2d_create(const jh_params* center_params, const jh_params* kp_pa
   pr->T = cfg->time_batch; pr->J = cfg->num_joints; pr->B = cfg->bbox;
   JH_REQUIRE(pr->T >= 1, "batch");
   JH_REQUIRE(cfg->img_w >= pr->B + 1 && cfg->img_h >= pr->B + 1, "image smaller than the bounding box");
+  JH_REQUIRE(cfg->precision >= JH_PRECISION_DEFAULT && cfg->precision <= JH_PRECISION_BF16X3_WIDE,
+             "jh_predictor_config.precision: unknown mode");
+  const int precision = cfg->precision == JH_PRECISION_DEFAULT ? precision_mode() : cfg->precision;
+  pr->cfg.precision = precision;
   pr->center.reset(new EffTrackPlan());
+  pr->center->precision = precision;
   if (pr->center->build(center_params->map, "", cfg->center_model, 1, pr->T, cfg->center_size,
                         cfg->center_size)) return 1;
   pr->kp.reset(new EffTrackPlan());
+  pr->kp->precision = precision;
   if (pr->kp->build(kp_params->map, "", cfg->kp_model, pr->J, pr->T, pr->B, pr->B)) return 1;
   if (pr->mem.get(reinterpret_cast<void**>(&pr->det), (size_t)pr->T * 3 * sizeof(float))) return 1;
   if (pr->mem.get(reinterpret_cast<void**>(&pr->chm), (size_t)pr->T * 2 * sizeof(int))) return 1;

@@ -31,24 +31,45 @@
 namespace jh {
 
 namespace {
-constexpr int kRC = 56, kRQ = kRC / 4, kRPX = 18, kRSA = kRC + 4;       // channels, quads, ring row width, A stride
-constexpr int kAFloats = 16 * kRSA;
+constexpr int kRPX = 18;                           // ring row width: 16 pixels + the depthwise halo
+// Geometry of the kernel for an RC-channel pyramid (56: the small model; 88: medium, round 4).  A lane owns one
+// channel quad and one of NSUB pixel slots: 14 quads x 4 slots = 56 active lanes at 56 channels, 22 x 2 = 44 at 88.
+template <int RC>
+struct RowGeo {
+  static constexpr int RQ = RC / 4;                // channel quads
+  static constexpr int NSUB = 64 / RQ;             // pixel slots per wave
+  static constexpr int NIT = (kRPX + NSUB - 1) / NSUB;   // items (pixels) of a fused row per lane
+  static constexpr int PPL = 16 / NSUB;            // depthwise output pixels per lane
+  static constexpr int RSA = RC + 4;               // operand-block row stride (floats): 16 rows on distinct banks
+  static constexpr int AFLOATS = 16 * RSA;
+  static constexpr int NCB = (RC + 15) / 16;       // 16-channel column blocks of the pointwise output
+  static constexpr int K8 = RC / 8;
+  // registers: 2 K8 NCB for the pointwise weights alone (56 at 56 channels, 132 at 88): two waves per SIMD fit
+  // at 56 channels, one at 88 (the kernel is bound by instruction issue, not by latency: DESIGN section 3)
+  static constexpr int WAVES = RC <= 56 ? 2 : 1;
+  static constexpr size_t lds_bytes() { return (size_t)(3 * kRPX * RC + AFLOATS + 9 * RC + NCB * 16) * sizeof(float); }
+  static_assert(RC % 8 == 0 && NSUB >= 1 && 16 % NSUB == 0, "channel count of the row-streaming node");
+};
 typedef float rf2 __attribute__((ext_vector_type(2)));
 typedef float rf4 __attribute__((ext_vector_type(4)));
 typedef unsigned ru4 __attribute__((ext_vector_type(4)));
 }  // namespace
 
-template <int NIN, int M1, int M2, int ACT, bool POOL = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void bifpn_rows_kernel(const NodeArgs a, int seg_rows, int strips) {
+template <int RC, int NIN, int M1, int M2, int ACT, bool POOL = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RowGeo<RC>::WAVES, RowGeo<RC>::WAVES)))
+void bifpn_rows_kernel(const NodeArgs a, int seg_rows, int strips) {
   static_assert(!POOL || NIN == 2, "the pooled row is parked in the (unused) depthwise-weight region of the LDS");
+  using GEO = RowGeo<RC>;
+  constexpr int kRC = RC, kRQ = GEO::RQ, NSUB = GEO::NSUB, NIT = GEO::NIT, PPL = GEO::PPL, kRSA = GEO::RSA;
+  constexpr int NCB = GEO::NCB, K8 = GEO::K8, kAFloats = GEO::AFLOATS;
   constexpr int kModes[3] = {FUSE_SAME, M1, M2};
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // byte offsets inside the wave's LDS: ring of three fused rows, operand block, depthwise weights
-  constexpr int kRowB = kRPX * kRC * 4;           // 4032
+  constexpr int kRowB = kRPX * kRC * 4;           // 4032 at 56 channels
   constexpr int kAtOff = 3 * kRowB, kDwOff = kAtOff + kAFloats * 4, kBiasOff = kDwOff + 9 * kRC * 4;
   const int lane = threadIdx.x;
-  const int q = lane % kRQ, sub = lane / kRQ;     // channel quad, pixel slot (0..3; 4 = idle lanes 56..63)
-  const bool act_lane = sub < 4;
+  const int q = lane % kRQ, sub = lane / kRQ;     // channel quad, pixel slot (0..NSUB-1; NSUB = the idle lanes)
+  const bool act_lane = sub < NSUB;
   const int c = q * 4;
   const int sx = blockIdx.x % strips, seg = blockIdx.x / strips, n = blockIdx.y;
   const int ox0 = sx * 16, y_begin = seg * seg_rows, y_end = min(a.H, y_begin + seg_rows);
@@ -91,13 +112,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   // pointwise weights of this lane for all 7 channel steps x 4 column blocks (registers for the whole strip);
   // the MFMAs run with the operands swapped (weights as A, pixels as B), so the accumulator of column block cb
   // holds, for pixel lane & 15, the four channels 16 cb + 4 (lane >> 4) .. + 3: one 16-byte store, no transposes
-  rf2 bw[kRC / 8][4];
+  rf2 bw[K8][NCB];
 #pragma unroll
-  for (int k8 = 0; k8 < kRC / 8; ++k8)
+  for (int k8 = 0; k8 < K8; ++k8)
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
-      bw[k8][cb] = *reinterpret_cast<const rf2*>(a.pw + ((size_t)(k8 * 4 + cb) * 64 + lane) * 2);
-  reinterpret_cast<float*>(smem + kBiasOff)[lane] = a.bias ? a.bias[lane] : 0.f;   // (bias: 64 floats, padded)
+    for (int cb = 0; cb < NCB; ++cb)
+      bw[k8][cb] = *reinterpret_cast<const rf2*>(a.pw + ((size_t)(k8 * NCB + cb) * 64 + lane) * 2);
+  for (int i = lane; i < NCB * 16; i += 64)       // (bias: cout_p16 = 16 NCB floats, padded)
+    reinterpret_cast<float*>(smem + kBiasOff)[i] = a.bias ? a.bias[i] : 0.f;
 
   __amdgpu_buffer_rsrc_t rs[NIN];
   int rowstep[NIN];                                // bytes per source row of input k
@@ -109,13 +131,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                                               0x00020000);
     rowstep[k] = (a.W >> sh) * kRC * 4;
   }
-  // the 5 items of this lane in a fused row (pixel it * 4 + sub of the 18): load offsets inside a source row
+  // the NIT items of this lane in a fused row (pixel it * NSUB + sub of the 18): load offsets inside a source row
   // (bit 31 = outside the image: the buffer load returns 0) and the 0 / 1 mask of the depthwise zero padding
-  int voff[NIN][5];
-  float msk[5];
+  int voff[NIN][NIT];
+  float msk[NIT];
 #pragma unroll
-  for (int it = 0; it < 5; ++it) {
-    const int px = it * 4 + sub, ix = ox0 - 1 + px;
+  for (int it = 0; it < NIT; ++it) {
+    const int px = it * NSUB + sub, ix = ox0 - 1 + px;
     const bool ok = act_lane && px < kRPX && (unsigned)ix < (unsigned)a.W;
     msk[it] = ok ? 1.f : 0.f;
 #pragma unroll
@@ -124,18 +146,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       voff[k][it] = ok ? ((ix >> sh) * kRC + c) * 4 : (int)0x80000000;
     }
   }
-  const int fdst = (sub * kRC + c) * 4;                         // + it * 4 pixels (imm) + ring slot
-  const int dsrc = (sub * 4 * kRC + c) * 4;                     // + ring slot + tap (imm)
-  const int adst = kAtOff + (sub * 4 * kRSA + c) * 4;           // + pixel (imm)
+  const int fdst = (sub * kRC + c) * 4;                         // + it * NSUB pixels (imm) + ring slot
+  const int dsrc = (sub * PPL * kRC + c) * 4;                   // + ring slot + tap (imm)
+  const int adst = kAtOff + (sub * PPL * kRSA + c) * 4;         // + pixel (imm)
   const int ard = kAtOff + (mrow * kRSA) * 4 + kq * 8;          // + channel step (imm)
   // Output through a buffer descriptor of image n: lanes whose four channels lie past cout_p (the padding of the
   // last column block) store with bit 31 set in the offset -- dropped by the range check -- instead of under a
   // branch: a store the compiler cannot count makes every later wait for loads a wait for ALL memory operations.
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
       a.y + (size_t)n * a.H * a.W * a.cout_p, 0, (int)((size_t)a.H * a.W * a.cout_p * 4), 0x00020000);
-  int yoff[4];
+  int yoff[NCB];
 #pragma unroll
-  for (int cb = 0; cb < 4; ++cb)
+  for (int cb = 0; cb < NCB; ++cb)
     yoff[cb] = cb * 16 + kq * 4 < a.cout_p ? ((ox0 + mrow) * a.cout_p + cb * 16 + kq * 4) * 4 : (int)0x80000000;
 
   // (one raw row in flight per wave: a second register set -- loads of row yf + 2 behind the fusion of row yf -- was
@@ -152,8 +174,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                                            (int)((size_t)(a.H >> 1) * (a.W >> 1) * a.cout_p * 4), 0x00020000);
     if (!(mrow & 1)) pbase = (((ox0 + mrow) >> 1) * a.cout_p + kq * 4) * 4;
   }
-  const int pool_lds = kDwOff + ((mrow >> 1) * kRC + kq * 4) * 4;          // + 64 * cb (channels < 56 only)
-  rf4 raw[NIN][5];
+  const int pool_lds = kDwOff + ((mrow >> 1) * kRC + kq * 4) * 4;          // + 64 * cb (channels < RC only)
+  rf4 raw[NIN][NIT];
   // An up-sampled input changes its source row only every 2nd output row: when the requested row is ODD its
   // registers are simply kept (5 load instructions less).  `all_c` is a compile-time flag -- the row loop is
   // unrolled by two -- because a load under a run-time branch makes the compiler's in-order wait counts
@@ -169,7 +191,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // (item-major: the fusion consumes item 0 of every input first, the in-order counter then releases it
     //  after the first NIN loads instead of after most of the row)
 #pragma unroll
-    for (int it = 0; it < 5; ++it)
+    for (int it = 0; it < NIT; ++it)
 #pragma unroll
       for (int k = 0; k < NIN; ++k)
         if (all || kModes[k] == FUSE_SAME)
@@ -181,13 +203,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     unsigned char* dst = smem + slot * kRowB + fdst;
     if ((unsigned)yf >= (unsigned)a.H) {                             // (uniform) padding row
 #pragma unroll
-      for (int it = 0; it < 5; ++it)
-        if (act_lane && (it < 4 || sub < 2))
-          *reinterpret_cast<rf4*>(dst + it * 4 * kRC * 4) = (rf4){0.f, 0.f, 0.f, 0.f};
+      for (int it = 0; it < NIT; ++it)
+        if (act_lane && it * NSUB + sub < kRPX)
+          *reinterpret_cast<rf4*>(dst + it * NSUB * kRC * 4) = (rf4){0.f, 0.f, 0.f, 0.f};
       return;
     }
 #pragma unroll
-    for (int it = 0; it < 5; ++it) {
+    for (int it = 0; it < NIT; ++it) {
       rf4 v = bb;
 #pragma unroll
       for (int k = 0; k < NIN; ++k) v = __builtin_elementwise_fma(raw[k][it], ak[k], v);
@@ -198,15 +220,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
       }
-      // (items 1..3 are always inside the image: W >= 32, only the strip's first and last columns can be padding)
-      if (it == 0 || it == 4) v *= (rf4){msk[it], msk[it], msk[it], msk[it]};
-      if (act_lane && (it < 4 || sub < 2)) *reinterpret_cast<rf4*>(dst + it * 4 * kRC * 4) = v;
+      // (the items in between are always inside the image: W >= 32, only the strip's first and last columns --
+      //  pixels 0 and 17, i.e. the first and the last item -- can be padding)
+      if (it == 0 || it == NIT - 1) v *= (rf4){msk[it], msk[it], msk[it], msk[it]};
+      if (act_lane && it * NSUB + sub < kRPX) *reinterpret_cast<rf4*>(dst + it * NSUB * kRC * 4) = v;
     }
   };
 
-  rf4 s1[4], s2[4];
+  rf4 s1[NCB], s2[NCB];
 #pragma unroll
-  for (int cb = 0; cb < 4; ++cb) { s1[cb] = (rf4){0.f, 0.f, 0.f, 0.f}; s2[cb] = s1[cb]; }
+  for (int cb = 0; cb < NCB; ++cb) { s1[cb] = (rf4){0.f, 0.f, 0.f, 0.f}; s2[cb] = s1[cb]; }
 
   // (everything the preamble loaded is waited for HERE: left pending, the compiler puts the wait at the first use
   //  inside the loop, where the in-order counter then also waits for the rows just requested)
@@ -221,7 +244,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int s_top = slot == 0 ? 1 : (slot == 1 ? 2 : 0);          // slot of row y - 1 = (slot + 1) % 3
     slot = s_top;                                 // (the next fused row replaces row y - 1 after this iteration)
     if (!decltype(out_c)::value) return;             // (the two rows above the segment's first output row)
-    // ---- depthwise 3x3: lane = (strip of 4 pixels, channel quad) -> operand block ----------------------
+    // ---- depthwise 3x3: lane = (strip of PPL pixels, channel quad) -> operand block --------------------
     if (act_lane) {
       int rs_ = s_top;                                               // ring slot of row y - 1 + dy
       const unsigned char* src[3];
@@ -234,7 +257,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       //  the live registers)
       constexpr int PXN = (kDwReg && !POOL) ? 4 : 2;        // (the pooled-output variant has no registers to spare)
 #pragma unroll
-      for (int part = 0; part < 4 / PXN; ++part) {
+      for (int part = 0; part < PPL / PXN; ++part) {
         rf4 d[PXN];
 #pragma unroll
         for (int i = 0; i < PXN; ++i) d[i] = (rf4){0.f, 0.f, 0.f, 0.f};
@@ -257,21 +280,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       }
     }
     // ---- pointwise 1x1: 64 output channels x 16 pixels x 56 channels on the matrix cores -------------------
-    f32x4 acc[4];
+    f32x4 acc[NCB];
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int cb = 0; cb < NCB; ++cb) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int k8 = 0; k8 < kRC / 8; ++k8) {
+    for (int k8 = 0; k8 < K8; ++k8) {
       const float2 xc = *reinterpret_cast<const float2*>(smem + ard + k8 * 32);
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[k8][cb][0], xc.x, acc[cb], 0, 0, 0);
+      for (int cb = 0; cb < NCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[k8][cb][0], xc.x, acc[cb], 0, 0, 0);
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[k8][cb][1], xc.y, acc[cb], 0, 0, 0);
+      for (int cb = 0; cb < NCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[k8][cb][1], xc.y, acc[cb], 0, 0, 0);
     }
     // ---- bias, statistics (in registers across the strip), one 16-byte store per column block ---------------
     const int yrow = y * a.W * a.cout_p * 4;
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
+    for (int cb = 0; cb < NCB; ++cb) {
       const rf4 b4 = *reinterpret_cast<const rf4*>(smem + kBiasOff + (cb * 16 + kq * 4) * 4);
       const rf4 v = (rf4){acc[cb][0], acc[cb][1], acc[cb][2], acc[cb][3]} + b4;
       s1[cb] += v;
@@ -282,7 +305,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           hm[j] = fmaxf(v[j], __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v[j]), 0xB1, 0xF, 0xF, true)));
-        const bool own = !(mrow & 1) && cb * 16 + kq * 4 < kRC;             // (cout == 56: checked by the launcher)
+        const bool own = !(mrow & 1) && cb * 16 + kq * 4 < kRC;             // (cout_p == RC: checked by the launcher)
         if (decltype(next_all_c)::value) {                                  // even output row: park
           if (own) *reinterpret_cast<rf4*>(smem + pool_lds + cb * 64) = hm;
         } else {                                                            // odd row: combine, store
@@ -290,8 +313,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
           if (own) pv = *reinterpret_cast<const rf4*>(smem + pool_lds + cb * 64);
 #pragma unroll
           for (int j = 0; j < 4; ++j) pv[j] = fmaxf(pv[j], hm[j]);
-          // (cout_p == 56: the last column block holds 8 channels, lanes kq >= 2 store nothing)
-          const int po = (cb == 3 && kq >= 2) ? (int)0x80000000 : pbase + cb * 64;
+          // (cout_p == RC: the last column block holds 8 channels, its lanes kq >= 2 store nothing)
+          const int po = cb * 16 + kq * 4 >= kRC ? (int)0x80000000 : pbase + cb * 64;
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ru4, pv), rp,
                                                  po + (y >> 1) * (a.W >> 1) * a.cout_p * 4, 0, 0);
         }
@@ -320,7 +343,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       return x;
     };
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
+    for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float t1 = row_sum(s1[cb][i]), t2 = row_sum(s2[cb][i]);
@@ -330,11 +353,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   }
 }
 
-// Which nodes take the row-streaming form: the 56-channel pyramid, 64 output channels' worth of column
-// blocks, no max-pooled input, level at least 32 pixels wide and a multiple of 16 (JH_NODE_ROWS=0: never).
+// Which nodes take the row-streaming form: the 56-channel (small model) or 88-channel (medium) pyramid with as many
+// output column blocks as the input has, no max-pooled input, level at least 32 pixels wide and a multiple of 16
+// (JH_NODE_ROWS=0: never; JH_NODE_ROWS88=0: not at 88 channels).
 bool bifpn_rows_eligible(const NodeArgs& a) {
   if (JH_ENV_KNOB("JH_NODE_ROWS") == 0 || a.rows == 0) return false;
-  if (a.Cp != kRC || a.cout_p16 != 64 || a.W % 16 != 0 || a.W < 32 || a.H < 16) return false;
+  if (a.Cp != 56 && !(a.Cp == 88 && JH_ENV_KNOB("JH_NODE_ROWS88") != 0)) return false;
+  if (a.cout_p16 != (a.Cp + 15) / 16 * 16 || a.W % 16 != 0 || a.W < 32 || a.H < 16) return false;
   if (a.mode[0] != FUSE_SAME) return false;
   if (a.rows < 0) {
     // (one wave per workgroup walking >= 10 rows: below ~2048 strips the chip is not filled and the tile form wins)
@@ -346,7 +371,8 @@ bool bifpn_rows_eligible(const NodeArgs& a) {
                          (a.mode[1] == FUSE_SAME && a.mode[2] == FUSE_SAME));
 }
 
-int launch_bifpn_rows(const NodeArgs& a, hipStream_t s) {
+template <int RC>
+static int launch_rows_rc(const NodeArgs& a, hipStream_t s) {
   const int strips = a.W / 16;
   // Rows per workgroup: a function of the node (image size, number of inputs) ONLY -- the float partial sums of the
   // statistics are taken per strip segment, so the segmentation must not depend on how many images a launch
@@ -358,11 +384,11 @@ int launch_bifpn_rows(const NodeArgs& a, hipStream_t s) {
   seg_rows = (seg_rows + 1) & ~1;                // (even: the kernel's row loop is unrolled by two on row parity)
   if (seg_rows > a.H) seg_rows = a.H;
   const int segs = (a.H + seg_rows - 1) / seg_rows;
-  const size_t lds = (size_t)(3 * kRPX * kRC + kAFloats + 9 * kRC + 64) * sizeof(float);
+  const size_t lds = RowGeo<RC>::lds_bytes();
   const dim3 grid(strips * segs, a.N);
 #define JH_ROWS(NIN, M1, M2, ACT, POOL) \
-  hipLaunchKernelGGL((bifpn_rows_kernel<NIN, M1, M2, ACT, POOL>), grid, dim3(64), lds, s, a, seg_rows, strips)
-  JH_REQUIRE(!a.y_pool || (a.n_in == 2 && a.act == ACT_SILU && a.cout_p == kRC && a.H % 2 == 0),
+  hipLaunchKernelGGL((bifpn_rows_kernel<RC, NIN, M1, M2, ACT, POOL>), grid, dim3(64), lds, s, a, seg_rows, strips)
+  JH_REQUIRE(!a.y_pool || (a.n_in == 2 && a.act == ACT_SILU && a.cout_p == RC && a.H % 2 == 0),
              "row-streaming node: pooled output");
   if (a.n_in == 2) {
     if (a.act == ACT_SILU && a.y_pool) JH_ROWS(2, FUSE_UP2, 0, ACT_SILU, true);
@@ -380,6 +406,11 @@ int launch_bifpn_rows(const NodeArgs& a, hipStream_t s) {
 #undef JH_ROWS
   JH_CHECK_HIP(hipGetLastError());
   return 0;
+}
+
+int launch_bifpn_rows(const NodeArgs& a, hipStream_t s) {
+  if (a.Cp == 88) return launch_rows_rc<88>(a, s);
+  return launch_rows_rc<56>(a, s);
 }
 
 }  // namespace jh

@@ -50,6 +50,10 @@ class Plan {
   int run(hipStream_t s);
   size_t launches() const { return ops_.size(); }
   size_t device_bytes() const { return bytes_; }
+  // Precision of the convolutions this plan builds (0 fp32, 1 bf16x3, 2 bf16x3_wide; include/jarvis_hip.h):
+  // the process default (jh_set_precision / JH_PRECISION) at construction; an owner with its own setting
+  // (jh_predictor_config::precision) overrides it before build().
+  int precision = precision_mode();
 
  protected:
   int alloc(void** p, size_t bytes);

@@ -116,17 +116,17 @@ int Plan::add_conv(const ParamMap& pm, const ConvDesc& d, const std::string& wke
   const int wino_variant = wino ? wino_variant_from_env() : 0;
   // precision mode bf16x3 (opt-in, jh_set_precision): the same layers on the bf16 matrix cores with
   // split operands (csrc/conv3d_bf16x3.hip)
-  const bool b3 = wino && precision_mode() >= 1;
+  const bool b3 = wino && precision >= 1;
   // ... and the keypoint head's ConvTranspose2d (no bias, no fused statistics, no gate)
   const bool d4b = d.nd == 2 && d.ostride > 1 && transposed && !b && !want_stats && !gate &&
-                   precision_mode() >= 1 && deconv4_bf16x3_eligible(d.cout);
+                   precision >= 1 && deconv4_bf16x3_eligible(d.cout);
   // ... and the dense k x k convolutions with a generic split-bf16 kernel (no gate; the 3-channel
   // network input keeps its own kernels)
   // Level 1 (bf16x3) takes the 3D one (V2V's stride-2 front convolution); the 2D trunk convolutions only
   // at level 2 (bf16x3_wide): split, they move the keypoints by up to 7.6e-4 mm on the fixture cases, which
   // leaves no margin under the 1e-3 mm bar.
   const bool xb = !wino && !d4b && !transposed && !gate && !se && conv_bf16x3_eligible(d) && x.Cp == cpad(d.cin) &&
-                  (precision_mode() == 2 || (precision_mode() == 1 && d.nd == 3));
+                  (precision == 2 || (precision == 1 && d.nd == 3));
   ConvWeights cw;
   if (xb) {
     if (pack_conv_bf16x3_weights(d, w, b, &cw)) return 1;
@@ -397,7 +397,7 @@ int EffTrackPlan::node(const ParamMap& pm, const std::string& cp, int n_in, cons
     // the row-streaming two-input form can write the 2x2-max-pooled raw output on the side (bifpn_rows.hip): the
     // bottom-up node of the next level then reads a same-resolution tensor with THIS node's statistics
     pooled->a = Act{};
-    if (n_in == 2 && act == ACT_SILU && out->a.Cp == 56 && like.H % 2 == 0 && bifpn_rows_eligible(a)) {
+    if (n_in == 2 && act == ACT_SILU && out->a.Cp == like.Cp && like.H % 2 == 0 && bifpn_rows_eligible(a)) {
       if (new_act(like.N, 1, like.H / 2, like.W / 2, cout, &pooled->a)) return 1;
       pooled->st = (long)st; pooled->inv = out->inv; pooled->act = out->act;
       a.y_pool = pooled->a.p;

@@ -16,13 +16,13 @@ from ..efficienttrack.efficienttrack import EfficientTrack
 
 
 class _Native2D:
-    def __init__(self, center_state, kp_state, cfg, img_h, img_w, batch):
+    def __init__(self, center_state, kp_state, cfg, img_h, img_w, batch, precision=None):
         c = N.PredictorConfig(
             1, cfg.KEYPOINTDETECT.NUM_JOINTS, int(cfg.CENTERDETECT.IMAGE_SIZE),
             cfg.KEYPOINTDETECT.BOUNDING_BOX_SIZE, 0.0, 0.0,
             arch.SIZE_IDS[cfg.CENTERDETECT.MODEL_SIZE], arch.SIZE_IDS[cfg.KEYPOINTDETECT.MODEL_SIZE],
             img_h, img_w, batch, 0, 0, 1, (ctypes.c_float * 3)(*cfg.DATASET.MEAN),
-            (ctypes.c_float * 3)(*cfg.DATASET.STD))
+            (ctypes.c_float * 3)(*cfg.DATASET.STD), N.precision_id(precision))
         self.T, self.J = batch, cfg.KEYPOINTDETECT.NUM_JOINTS
         self.handle = ctypes.c_void_p()
         pc, pk = N.Params(center_state), N.Params(kp_state)
@@ -49,11 +49,13 @@ class _Native2D:
 
 class JarvisPredictor2D(nn.Module):
     def __init__(self, cfg, weights_center_detect="latest", weights_keypoint_detect="latest",
-                 trt_mode="off"):
+                 trt_mode="off", precision=None):
         super().__init__()
-        if trt_mode != "off":
-            raise NotImplementedError("TensorRT modes do not exist on MI355X; the native HIP "
-                                      "path is always on")
+        # trt_mode 'new' / 'previous' (jarvis2D.py:39-43) select the reduced-precision mode bf16x3, see
+        # jarvis3D.precision_for_trt_mode
+        from .jarvis3D import precision_for_trt_mode
+        self.precision = precision_for_trt_mode(trt_mode, precision)
+        self.trt_mode = trt_mode
         self.cfg = cfg
         self.centerDetect = EfficientTrack("CenterDetectInference", cfg, weights_center_detect).model
         self.keypointDetect = EfficientTrack("KeypointDetectInference", cfg,
@@ -68,7 +70,7 @@ class JarvisPredictor2D(nn.Module):
         if key not in self._native:
             self._native[key] = _Native2D(flat_state(self.centerDetect),
                                           flat_state(self.keypointDetect), self.cfg, img_h, img_w,
-                                          batch)
+                                          batch, self.precision)
         return self._native[key]
 
     def forward(self, img):

@@ -20,13 +20,33 @@ from ..hybridnet.hybridnet import HybridNet
 from ..utils.reprojection import ReprojectionTool
 
 
+def precision_for_trt_mode(trt_mode, precision=None):
+    """The reference's `trt_mode` ('off' | 'new' | 'previous', utils/paramClasses.py:21,34; forwarded by the
+    drivers, prediction/predict3D.py:36-37) selects its half-precision TensorRT engines (jarvis3D.py:42-46,
+    93,107,122: enabled_precisions={torch.half}).  There are no engines to compile or load here -- the native
+    HIP path is always on -- so 'new' and 'previous' both select what stands in that seat: the labelled
+    reduced-precision mode bf16x3 (3D keypoints within 3e-4 mm of the fp32 reference on every fixture).
+    'off' = fp32, the parity mode.  An explicit `precision` wins over trt_mode; returns None for
+    "follow the process default" (`_native.set_precision`)."""
+    if trt_mode not in ("off", "new", "previous"):
+        raise ValueError("trt_mode must be 'off', 'new' or 'previous' (utils/paramClasses.py:21), got %r"
+                         % (trt_mode,))
+    if precision is not None:
+        return precision
+    if trt_mode != "off":
+        print("[Info] trt_mode='%s': no TensorRT on MI355X -- using the native reduced-precision mode "
+              "bf16x3 (split-bf16 MFMA, fp32 accumulate) in its place" % trt_mode)
+        return "bf16x3"
+    return None
+
+
 class JarvisPredictor3D(nn.Module):
     def __init__(self, cfg, weights_center_detect="latest", weights_hybridnet="latest",
-                 trt_mode="off"):
+                 trt_mode="off", precision=None):
         super().__init__()
-        if trt_mode != "off":
-            raise NotImplementedError("TensorRT modes do not exist on MI355X; the native HIP "
-                                      "path is always on")
+        # None: the process default (fp32 unless JH_PRECISION / set_precision says otherwise)
+        self.precision = precision_for_trt_mode(trt_mode, precision)
+        self.trt_mode = trt_mode
         self.cfg = cfg
         self.centerDetect = EfficientTrack("CenterDetectInference", cfg, weights_center_detect).model
         self.hybridNet = HybridNet("inference", cfg, weights_hybridnet).model
@@ -46,7 +66,7 @@ class JarvisPredictor3D(nn.Module):
             roi_cube_size=c.HYBRIDNET.ROI_CUBE_SIZE, grid_spacing=c.HYBRIDNET.GRID_SPACING,
             img_h=img_h, img_w=img_w, mean=list(c.DATASET.MEAN), std=list(c.DATASET.STD),
             center_model=c.CENTERDETECT.MODEL_SIZE, kp_model=c.KEYPOINTDETECT.MODEL_SIZE,
-            time_batch=time_batch, cam_lo=cam_lo, cam_n=cam_n)
+            time_batch=time_batch, cam_lo=cam_lo, cam_n=cam_n, precision=self.precision)
 
     def _fresh_cache(self):
         """Native predictors hold packed copies of the weights: drop them when any of the

@@ -9,11 +9,12 @@
 
 #include "jarvis_hip.h"
 
-_Static_assert(sizeof(jh_predictor_config) == 80, "jh_predictor_config layout (mirrored in _native.py)");
+_Static_assert(sizeof(jh_predictor_config) == 84, "jh_predictor_config layout (mirrored in _native.py)");
 _Static_assert(offsetof(jh_predictor_config, roi_cube_size) == 16, "roi_cube_size offset");
 _Static_assert(offsetof(jh_predictor_config, time_batch) == 40, "time_batch offset");
 _Static_assert(offsetof(jh_predictor_config, mean) == 56, "mean offset");
 _Static_assert(offsetof(jh_predictor_config, std) == 68, "std offset");
+_Static_assert(offsetof(jh_predictor_config, precision) == 80, "precision offset");
 
 int main(void) {
   jh_params* p = NULL;

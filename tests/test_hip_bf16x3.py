@@ -240,3 +240,58 @@ def test_predictor3d_bf16x3_wide(golden, bf16x3):
         report("predictor3d_bf16x3_wide", tag=tag, points_mm=ep)
         worst = max(worst, ep)
     assert worst < 2e-3
+
+
+def test_precision_is_a_property_of_the_predictor(golden):
+    """jh_predictor_config.precision (ABI v4): an fp32 and a bf16x3 predictor built in EITHER order in one process,
+    with the process default left at fp32, give the results of the process-wide switch; the reference's
+    `trt_mode='new' | 'previous'` (jarvis3D.py:42-46, utils/paramClasses.py:21) selects bf16x3 instead of raising."""
+    from jarvis_hybridnet_amd import _native as N
+    from jarvis_hybridnet_amd import synthetic as S
+    from jarvis_hybridnet_amd._predictor import NativePredictor
+    from jarvis_hybridnet_amd.prediction.jarvis3D import JarvisPredictor3D
+    from tests.test_hip_predictor import make_cfg
+    assert N.get_precision() == "f32"
+    c = cases.PREDICTOR_CASES["cfg2"]
+    inp = cases.predictor_inputs("cfg2")
+    kw = dict(num_cameras=c["C"], num_joints=c["J"], center_size=c["center_size"], bbox=c["bbox"],
+              roi_cube_size=c["roi"], grid_spacing=c["spacing"], img_h=c["H"], img_w=c["W"],
+              mean=S.MEAN, std=S.STD, time_batch=1)
+    dev = [cuda(t) for t in (inp["cam"], inp["intr"], inp["dist"])]
+    x = cuda(inp["imgs"]).unsqueeze(0).contiguous()
+
+    def run(p):
+        p.set_calibration(*dev)
+        out = [t.clone() for t in p.forward(x)]
+        torch.cuda.synchronize()
+        return out
+    b1 = NativePredictor(inp["sd_center"], inp["sd_hybrid"], precision="bf16x3", **kw)
+    f1 = NativePredictor(inp["sd_center"], inp["sd_hybrid"], precision="f32", **kw)
+    b2 = NativePredictor(inp["sd_center"], inp["sd_hybrid"], precision="bf16x3", **kw)
+    dflt = NativePredictor(inp["sd_center"], inp["sd_hybrid"], **kw)
+    assert (b1.precision, f1.precision, b2.precision, dflt.precision) == ("bf16x3", "f32", "bf16x3", "f32")
+    ob1, of1, ob2, od = run(b1), run(f1), run(b2), run(dflt)
+    assert torch.equal(ob1[0], ob2[0]) and torch.equal(of1[0], od[0])      # independent of creation order
+    assert not torch.equal(ob1[0], of1[0])                                 # and really different kernels
+    prev = N.set_precision("bf16x3")                                       # the process-wide switch = the default only
+    try:
+        via_default = NativePredictor(inp["sd_center"], inp["sd_hybrid"], **kw)
+        explicit_f32 = NativePredictor(inp["sd_center"], inp["sd_hybrid"], precision="f32", **kw)
+    finally:
+        N.set_precision(prev)
+    assert via_default.precision == "bf16x3" and explicit_f32.precision == "f32"
+    assert torch.equal(run(via_default)[0], ob1[0]) and torch.equal(run(explicit_f32)[0], of1[0])
+    # the trt_mode seam of the reference's constructor
+    g = golden("predictor")
+    gold = torch.from_numpy(g["cfg2.points3D"])
+    for mode in ("new", "previous"):
+        jp = JarvisPredictor3D(make_cfg(c, c["center_size"]), inp["sd_center"], inp["sd_hybrid"], mode)
+        pts, conf = jp(cuda(inp["imgs"]), *dev)
+        torch.cuda.synchronize()
+        assert jp.precision == "bf16x3" and jp.native(c["H"], c["W"]).precision == "bf16x3"
+        assert torch.equal(pts[0], ob1[0][0])
+        assert max_err(pts, gold) < 1e-3
+    off = JarvisPredictor3D(make_cfg(c, c["center_size"]), inp["sd_center"], inp["sd_hybrid"], "off")
+    assert off.precision is None and torch.equal(off(cuda(inp["imgs"]), *dev)[0][0], of1[0][0])
+    with pytest.raises(ValueError, match="trt_mode"):
+        JarvisPredictor3D(make_cfg(c, c["center_size"]), inp["sd_center"], inp["sd_hybrid"], "fast")

@@ -200,6 +200,13 @@ NODE_CASES = [  # (C, Cout, H, W, modes, act, n): the node shapes of the small /
     (56, 56, 32, 32, (0, 1), 2, 256),       # P4 top-down, 8-row segments
     (56, 56, 48, 32, (0, 1), 2, 192),       # height that is not a power of two
     (56, 56, 32, 32, (0, 0, 0), 2, 256),    # P4 bottom-up when P3's node has written its pooled output: three same-level inputs
+    # the medium model's 88-channel pyramid in the row-streaming form (22 channel quads x 2 pixel slots per wave,
+    # 6 output column blocks, one wave per SIMD)
+    (88, 88, 64, 64, (0, 1), 2, 64),        # P3 top-down
+    (88, 88, 64, 64, (0, 1, 2), 0, 64),     # head: first_conv 88 -> 88, no activation
+    (88, 88, 32, 32, (0, 1), 2, 256),       # P4 top-down
+    (88, 88, 32, 32, (0, 0, 0), 2, 256),    # P4 bottom-up with three same-level inputs
+    (88, 88, 48, 32, (0, 1), 2, 192),       # ragged height
 ]
 
 

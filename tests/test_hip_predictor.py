@@ -80,12 +80,13 @@ def test_predictor3d(tag, golden):
     assert ec < 1e-4
 
 
-@pytest.mark.parametrize("tag", ["ex72", "cfg3"])
+@pytest.mark.parametrize("tag", ["ex72", "cfg3", "cfg3_medium"])
 def test_predictor3d_time_batch_8_vs_fixture(tag, golden):
     """The time_batch >= 8 class (row-streaming BiFPN nodes: the form bench.py times) held to the REFERENCE fixture
     directly: frame 0 of an 8-frame-set call is the fixture case; the other seven are distinct subjects and
     must agree with their single-frame calls.  ex72 = the reference's shipped geometry (72^3 grid: cube gather on
-    a grid that is not a multiple of 16, V2V at 36^3 / 18^3 with partial Winograd tiles)."""
+    a grid that is not a multiple of 16, V2V at 36^3 / 18^3 with partial Winograd tiles); cfg3_medium = the
+    reference's default model size, whose 88-channel pyramid runs the row-streaming nodes from time_batch 8 on."""
     from jarvis_hybridnet_amd import synthetic as S
     from jarvis_hybridnet_amd.prediction.jarvis3D import JarvisPredictor3D
     c = cases.PREDICTOR_CASES[tag]

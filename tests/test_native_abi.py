@@ -25,7 +25,7 @@ def test_library_exports_header_symbols():
     for name in names:
         assert hasattr(lib, name), "libjarvis_hip.so lacks " + name
     assert names == N.symbols(), "ctypes table and header disagree"
-    assert lib.jh_abi_version() == N.ABI_VERSION == 3
+    assert lib.jh_abi_version() == N.ABI_VERSION == 4
     assert lib.jh_last_error() is not None
 
 
