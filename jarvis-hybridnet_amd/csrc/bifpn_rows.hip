@@ -46,6 +46,8 @@ struct RowGeo {
   static constexpr int K8 = RC / 8;
   // registers: 2 K8 NCB for the pointwise weights alone (56 at 56 channels, 132 at 88): two waves per SIMD fit
   // at 56 channels, one at 88 (the kernel is bound by instruction issue, not by latency: DESIGN section 3)
+  // (56 channels with ONE wave per SIMD and the freed registers spent on depthwise weights in registers / four
+  //  pixels per pass in every variant: 257 instead of 219 us at P3 -- the second wave's latency hiding is worth more)
   static constexpr int WAVES = RC <= 56 ? 2 : 1;
   static constexpr size_t lds_bytes() { return (size_t)(3 * kRPX * RC + AFLOATS + 9 * RC + NCB * 16) * sizeof(float); }
   static_assert(RC % 8 == 0 && NSUB >= 1 && 16 % NSUB == 0, "channel count of the row-streaming node");

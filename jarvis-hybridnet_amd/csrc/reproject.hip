@@ -301,7 +301,6 @@ __global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
   constexpr int TPT = (NTAB + NT - 1) / NT;         // table entries staged per thread
   constexpr int JPB = Q * 16;                       // bytes per heatmap pixel in memory
   constexpr int SPX = Q + 1;                        // 16-byte slots per staged pixel in LDS
-  constexpr int NR = (80 * 1024) / (NT * 16);       // NT-slot rounds of one patch (budget: a.patch_bytes)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float2* ctab = reinterpret_cast<float2*>(smem);   // [2][NTAB] cube-local coarse (u, v) of two cameras
   constexpr int kZeroOff = 2 * NTAB * 8;            // one all-zero pixel (the virtual border)
@@ -392,7 +391,7 @@ __global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
   }
 
   // patch geometry of one camera (uniform values): box origin, width, height, odd LDS row pitch
-  struct Geo { int x0, y0, pw, ph, pwp, slots, big; float rcp_spx_pwp; };
+  struct Geo { int x0, y0, pw, ph, pwp, slots, big; };
   auto geometry = [&](int4 b) __attribute__((always_inline)) {
     Geo g;
     g.x0 = __builtin_amdgcn_readfirstlane(b.x); g.y0 = __builtin_amdgcn_readfirstlane(b.y);
@@ -400,15 +399,21 @@ __global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
     g.pwp = g.pw | 1;
     g.slots = g.ph * g.pwp * SPX;                        // 16-byte LDS slots
     g.big = g.slots * 16 > a.patch_limit;
-    g.rcp_spx_pwp = 1.0f / (float)(g.pwp * SPX);
     return g;
   };
   auto box = [&](int c) __attribute__((always_inline)) {
     return *reinterpret_cast<const int4*>(smem + kGeoOff + min(c, C - 1) * 16);
   };
-  auto cam_base = [&](int c) __attribute__((always_inline)) {
-    const int cblk = c / a.lay.cams_per_block, cloc = c - cblk * a.lay.cams_per_block;
-    return heat_t + (size_t)cblk * a.lay.block_stride + (size_t)cloc * (plane_bytes >> 2);
+  // heatmap plane of a camera: camera c lives at block c / cams_per_block, local camera c % cams_per_block of the
+  // (blocks, frames, cameras) layout.  Walked incrementally -- a run-time integer division per camera is ~28
+  // vector instructions even for a uniform value, and the kernel is bound by vector-instruction issue.
+  struct CamPos { int blk, loc; };
+  auto cam_next = [&](CamPos p) __attribute__((always_inline)) {
+    if (++p.loc == a.lay.cams_per_block) { p.loc = 0; ++p.blk; }
+    return p;
+  };
+  auto cam_base = [&](CamPos p) __attribute__((always_inline)) {
+    return heat_t + (size_t)p.blk * a.lay.block_stride + (size_t)p.loc * (plane_bytes >> 2);
   };
   // where the taps of camera c (geometry g) of this lane's voxels are: an LDS byte offset (>= 0) or
   // bit 31 + the byte offset inside the camera's heatmap (that lane then reads global memory)
@@ -450,24 +455,40 @@ __global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
       __builtin_amdgcn_sched_barrier(0);                 // one voxel at a time: register pressure
     }
   };
-  // patch of camera c -> LDS buffer c & 1.  LDS slot s (16 bytes) = quad s % SPX of staged pixel
-  // s / SPX (row-major, pitch pwp); global_load_lds writes at wave-uniform base + 16 * lane, so lane
-  // <-> slot; pad slots and slots past the end are masked off
-  auto load_patch = [&](int c, const Geo& g) __attribute__((always_inline)) {
+  // patch of camera c -> LDS buffer c & 1.  LDS slot s (16 bytes) of a patch row = quad s % SPX of staged pixel
+  // s / SPX; rows have a pitch of pwp pixels.  One WAVE stages one row at a time (rows w, w + waves, ...):
+  // global_load_lds writes at a wave-uniform LDS base + 16 * lane, so within a round of 64 slots lane <-> slot,
+  // and the pixels of a heatmap row are contiguous in memory -- a lane's source offset inside the row,
+  // px * JPB + quad * 16, is a CONSTANT of the lane and the round (kept in registers for the first four rounds =
+  // rows of up to 256 slots), pad slots carry an offset that fails the one range check `offset < pw * JPB`.
+  // (Round 3 linearised the whole patch over the workgroup: a float multiply, two integer divisions and four
+  // compares per slot -- a third of the kernel's vector instructions, and the kernel is bound by their issue.)
+  constexpr int kPre = 4;
+  int goff[kPre];
+#pragma unroll
+  for (int r = 0; r < kPre; ++r) {
+    const int slot = r * 64 + lane, px = slot / SPX, quad = slot - px * SPX;
+    goff[r] = quad < Q ? px * JPB + quad * 16 : 0x7fffffff;
+  }
+  auto load_patch = [&](int c, CamPos cp, const Geo& g) __attribute__((always_inline)) {
     typedef __attribute__((address_space(3))) void lds_void;
     typedef const __attribute__((address_space(1))) void glb_void;
-    unsigned char* dst = smem + kPatchOff + (c & 1) * a.patch_bytes + (size_t)(tid & ~63) * 16;
-    const char* src = reinterpret_cast<const char*>(cam_base(c));
+    const int rowslots = g.pwp * SPX, wlim = g.pw * JPB;                     // uniform
+    const char* src = reinterpret_cast<const char*>(cam_base(cp)) + ((size_t)g.y0 * Hh + g.x0) * JPB;
+    unsigned char* dst = smem + kPatchOff + (c & 1) * a.patch_bytes;
 #pragma nounroll
-    for (int r = 0; r < NR; ++r) {
-      if (r * NT < g.slots) {                                               // uniform
-        const int sl = r * NT + tid;
-        const int row = (int)(((float)sl + 0.5f) * g.rcp_spx_pwp);
-        const int rem = sl - row * (g.pwp * SPX);
-        const int px = rem / SPX, quad = rem - px * SPX;
-        if (sl < g.slots && quad < Q && px < g.pw)
-          __builtin_amdgcn_global_load_lds((glb_void*)(src + ((size_t)((g.y0 + row) * Hh + g.x0 + px)) * JPB + quad * 16),
-                                           (lds_void*)(dst + r * NT * 16), 16, 0, 0);
+    for (int row = w; row < g.ph; row += NT / 64) {                          // uniform
+      const char* srow = src + (size_t)row * Hh * JPB;
+      unsigned char* drow = dst + (size_t)row * rowslots * 16;
+#pragma unroll
+      for (int r = 0; r < kPre; ++r)
+        if (r * 64 < rowslots && goff[r] < wlim)
+          __builtin_amdgcn_global_load_lds((glb_void*)(srow + goff[r]), (lds_void*)(drow + r * 1024), 16, 0, 0);
+#pragma nounroll
+      for (int r = kPre; r * 64 < rowslots; ++r) {                           // (rows wider than 256 slots: rare)
+        const int slot = r * 64 + lane, px = slot / SPX, quad = slot - px * SPX;
+        if (quad < Q && px < g.pw)
+          __builtin_amdgcn_global_load_lds((glb_void*)(srow + px * JPB + quad * 16), (lds_void*)(drow + r * 1024), 16, 0, 0);
       }
     }
   };
@@ -481,7 +502,8 @@ __global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
     }
   __syncthreads();
   Geo gc = geometry(box(0));
-  if (!gc.big) load_patch(0, gc);
+  CamPos cam_c{0, 0};                                  // camera c of the loop below
+  if (!gc.big) load_patch(0, cam_c, gc);
   int4 box_n = box(1);                                // (a box is fetched one camera ahead of its use)
   int off_c[VPT];
   tap_offsets(0, gc, off_c);
@@ -497,17 +519,18 @@ __global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
     // camera c+1: box, patch in flight into the other buffer; camera c+2: table entry in flight
     Geo gn = gc;
     const bool more = c + 1 < C;
+    const CamPos cam_n = cam_next(cam_c);
     if (more) {
       if (!(a.abl & 64)) gn = geometry(box_n);
       box_n = box(c + 2);
-      if (!gn.big && !(a.abl & 1)) load_patch(c + 1, gn);
+      if (!gn.big && !(a.abl & 1)) load_patch(c + 1, cam_n, gn);
     }
     float2 tv[TPT];
 #pragma unroll
     for (int e = 0; e < TPT; ++e)
       if (c + 2 < C && e * NT + tid < NTAB && !(a.abl & 16)) tv[e] = a.coarse[(size_t)(t * C + c + 2) * nvox_c + ctab_src[e]];
     // gather camera c: every lane reads the Q quads of its own voxels' pixels
-    const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cam_base(c)), 0,
+    const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cam_base(cam_c)), 0,
                                                                            plane_bytes, 0x00020000);
     if (!(a.abl & 2))
 #pragma unroll
@@ -546,6 +569,7 @@ __global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
     // nobody still reads patch c, whose buffer the next iteration's prefetch overwrites
     if (!(a.abl & 128)) __syncthreads();
     gc = gn;
+    cam_c = cam_n;
   }
 
   // ---- mean over cameras, / 255 (see repro_gather_kernel); a lane stores its voxels' Jp channels ----
