@@ -176,7 +176,13 @@ int jh_predictor_stage_keypoints(jh_predictor* pr, const float* frames_dev,
 /* Stage 3 (model.py:65-88) for the time_batch_3d frames t0 .. t0+T3-1 of the
  * batch: heat_all (T3,C,B/2,B/2,Jp) of ALL cameras for those frames -> points
  * (T3,J,3), conf (T3,J), valid (T3) int32 (0 = fewer than two cameras saw the
- * subject: the reference returns (None, None), jarvis3D.py:187-190). */
+ * subject: the reference returns (None, None), jarvis3D.py:187-190).
+ * Pipelining: a predictor keeps TWO sets of (crop centres, truncated 3D centre, validity).  Every
+ * stage-2 call (jh_predictor_stage_keypoints*) writes the set the previous stage-2 call did not; a
+ * stage-3 call reads the set of the stage-2 call that preceded it in HOST CALL ORDER.  Stage 3 of
+ * time batch i may therefore run on a second stream concurrently with stage 2 of batch i+1 -- they
+ * share no buffer -- provided the caller orders (events) stage 3 of batch i before stage 2 of batch
+ * i+2 and keeps heat_all alive until stage 3 has read it (jarvis_hybridnet_amd/distributed.py). */
 int jh_predictor_stage_3d(jh_predictor* pr, const float* heat_all_dev, int t0, float* points_dev,
                           float* conf_dev, int32_t* valid_dev, void* stream);
 /* Stage 2 fed directly from the all-gather of the per-rank detections (new design, no

@@ -286,7 +286,16 @@ struct jh_predictor {
   Scratch mem;
   float *cam = nullptr, *intr = nullptr, *dist = nullptr;
   float *det_all = nullptr, *c3f = nullptr;
-  int *c3i = nullptr, *chm = nullptr, *valid = nullptr;
+  // Crop centres, truncated 3D centre and validity of a time batch: written by stage 2 (triangulation), read by
+  // stage 3.  TWO sets: the staged entry points alternate between them, so that stage 3 of time batch i may run
+  // on a second stream while stage 2 of batch i+1 (which writes the other set) is under way -- a stage-3 call
+  // reads the set of the stage-2 call that preceded it in host call order (distributed.py).  The whole-path
+  // forward always uses set 0 (its captured graph bakes the pointers).
+  int *c3i_[2] = {nullptr, nullptr}, *chm_[2] = {nullptr, nullptr}, *valid_[2] = {nullptr, nullptr};
+  int slot = 0;
+  int* c3i_cur() const { return c3i_[slot]; }
+  int* chm_cur() const { return chm_[slot]; }
+  int* valid_cur() const { return valid_[slot]; }
   float2* coarse = nullptr;
   double* sa_partial = nullptr;
   int* sa_max = nullptr;
@@ -309,12 +318,12 @@ struct jh_predictor {
     const double g3 = (double)G * G * G;
     // algorithmic traffic of the gather: every heatmap byte once in, the volume once out
     JH_PROF("reproject_gather", 0.0, 4.0 * T3 * ((double)C * Hh * Hh * J + g3 * J),
-            launch_reproject(cam, intr, dist, c3i + t0 * 3, chm + t0 * C * 2, heat_all, coarse,
+            launch_reproject(cam, intr, dist, c3i_cur() + t0 * 3, chm_cur() + t0 * C * 2, heat_all, coarse,
                              v2v->input.p, nullptr, T3, C, G, cfg.grid_spacing, hs, Jp,
                              /*heat_pad=*/0, /*div255=*/1, s, layout));
     if (v2v->run(s)) return 1;
     JH_PROF("softargmax", 0.0, 4.0 * T3 * (g3 / 8) * J,
-            launch_softargmax(v2v->output.p, c3i + t0 * 3, sa_partial, sa_max, points, conf,
+            launch_softargmax(v2v->output.p, c3i_cur() + t0 * 3, sa_partial, sa_max, points, conf,
                               heatmap_final, T3, J, Jp, Gh, cfg.grid_spacing, cfg.roi_cube_size, s));
     return 0;
   }
@@ -366,9 +375,11 @@ int jh_predictor_create(const jh_params* center_params, const jh_params* hybrid_
   if (m.get(reinterpret_cast<void**>(&pr->dist), (size_t)C * 5 * sizeof(float))) return 1;
   if (m.get(reinterpret_cast<void**>(&pr->det_all), (size_t)T * C * 3 * sizeof(float))) return 1;
   if (m.get(reinterpret_cast<void**>(&pr->c3f), (size_t)T * 3 * sizeof(float))) return 1;
-  if (m.get(reinterpret_cast<void**>(&pr->c3i), (size_t)T * 3 * sizeof(int))) return 1;
-  if (m.get(reinterpret_cast<void**>(&pr->chm), (size_t)T * C * 2 * sizeof(int))) return 1;
-  if (m.get(reinterpret_cast<void**>(&pr->valid), (size_t)T * sizeof(int))) return 1;
+  for (int k = 0; k < 2; ++k) {
+    if (m.get(reinterpret_cast<void**>(&pr->c3i_[k]), (size_t)T * 3 * sizeof(int))) return 1;
+    if (m.get(reinterpret_cast<void**>(&pr->chm_[k]), (size_t)T * C * 2 * sizeof(int))) return 1;
+    if (m.get(reinterpret_cast<void**>(&pr->valid_[k]), (size_t)T * sizeof(int))) return 1;
+  }
   if (m.get(reinterpret_cast<void**>(&pr->coarse),
             (size_t)pr->T3 * C * pr->Gh * pr->Gh * pr->Gh * sizeof(float2))) return 1;
   {   // soft-argmax accumulators and maxima in ONE allocation (zeroed by one launch per forward)
@@ -376,7 +387,7 @@ int jh_predictor_create(const jh_params* center_params, const jh_params* hybrid_
     if (m.get(reinterpret_cast<void**>(&pr->sa_partial), pb + mb)) return 1;
     pr->sa_max = reinterpret_cast<int*>(reinterpret_cast<char*>(pr->sa_partial) + pb);
   }
-  JH_CHECK_HIP(hipMemset(pr->valid, 0, (size_t)T * sizeof(int)));
+  for (int k = 0; k < 2; ++k) JH_CHECK_HIP(hipMemset(pr->valid_[k], 0, (size_t)T * sizeof(int)));
   // graph replay: by default for the single-frame-set call (T = 1), where the forward is
   // launch-bound; JH_GRAPH=1 / 0 forces it on / off for every time batch
   const int knob = JH_ENV_KNOB("JH_GRAPH");
@@ -460,9 +471,10 @@ int jh_predictor_stage_center_u8(jh_predictor* pr, const uint8_t* frames_dev, fl
 
 static int stage_keypoints_impl(jh_predictor* pr, const void* frames_dev, int src_u8,
                                 const float* det_all_dev, float* heat_dev, void* stream,
-                                int det_blocks = 1) {
+                                int det_blocks = 1, bool next_centre_set = false) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   const auto& c = pr->cfg;
+  if (next_centre_set) pr->slot ^= 1;        // (the staged API: the previous batch's stage 3 may still read the other set)
   if (det_blocks > 1) {
     JH_REQUIRE(pr->C % det_blocks == 0, "cameras must divide evenly over the detection blocks");
     const int n = pr->T * pr->C * 3;
@@ -475,8 +487,8 @@ static int stage_keypoints_impl(jh_predictor* pr, const void* frames_dev, int sr
   const float sx2 = (float)((double)c.img_w / (double)c.center_size) * 2.f;
   const float sy2 = (float)((double)c.img_h / (double)c.center_size) * 2.f;
   JH_PROF("triangulate", 0.0, 0.0,
-          launch_triangulate(det_all_dev, pr->cam, pr->intr, pr->dist, pr->c3f, pr->c3i, pr->chm,
-                             pr->valid, pr->T, pr->C, sx2, sy2, 255.f, pr->B / 2, c.img_w, c.img_h, s));
+          launch_triangulate(det_all_dev, pr->cam, pr->intr, pr->dist, pr->c3f, pr->c3i_cur(), pr->chm_cur(),
+                             pr->valid_cur(), pr->T, pr->C, sx2, sy2, 255.f, pr->B / 2, c.img_w, c.img_h, s));
   if (det_all_dev != pr->det_all)
     JH_CHECK_HIP(hipMemcpyAsync(pr->det_all, det_all_dev, (size_t)pr->T * pr->C * 3 * sizeof(float),
                                 hipMemcpyDeviceToDevice, s));
@@ -484,12 +496,12 @@ static int stage_keypoints_impl(jh_predictor* pr, const void* frames_dev, int sr
     // crop + normalise happen inside the stem convolution's patch staging (csrc/stem.hip)
     StemSource& src = pr->kp->stem_src;
     src.mode = 2; src.frames = frames_dev; src.frames_cell = pr->cur_cell; src.src_u8 = src_u8;
-    src.center_hm = pr->chm; src.Cloc = pr->Cloc; src.C = pr->C; src.cam0 = c.cam_lo;
+    src.center_hm = pr->chm_cur(); src.Cloc = pr->Cloc; src.C = pr->C; src.cam0 = c.cam_lo;
     src.H = c.img_h; src.W = c.img_w;
     for (int i = 0; i < 3; ++i) { src.mean[i] = c.mean[i]; src.stdv[i] = c.std[i]; }
   } else {
     JH_PROF("preprocess_crop", 0.0, (double)pr->T * pr->Cloc * pr->B * pr->B * (src_u8 ? 15.0 : 24.0),
-            launch_preprocess_crop(frames_dev, src_u8, pr->chm, pr->kp->input.p, pr->T, pr->Cloc, pr->C,
+            launch_preprocess_crop(frames_dev, src_u8, pr->chm_cur(), pr->kp->input.p, pr->T, pr->Cloc, pr->C,
                                    c.cam_lo, c.img_h, c.img_w, pr->B, c.mean, c.std, s, pr->cur_cell));
   }
   if (pr->kp->run(s)) return 1;
@@ -501,18 +513,18 @@ static int stage_keypoints_impl(jh_predictor* pr, const void* frames_dev, int sr
 
 int jh_predictor_stage_keypoints(jh_predictor* pr, const float* frames_dev,
                                  const float* det_all_dev, float* heat_dev, void* stream) {
-  return stage_keypoints_impl(pr, frames_dev, 0, det_all_dev, heat_dev, stream);
+  return stage_keypoints_impl(pr, frames_dev, 0, det_all_dev, heat_dev, stream, 1, true);
 }
 int jh_predictor_stage_keypoints_u8(jh_predictor* pr, const uint8_t* frames_dev,
                                     const float* det_all_dev, float* heat_dev, void* stream) {
-  return stage_keypoints_impl(pr, frames_dev, 1, det_all_dev, heat_dev, stream);
+  return stage_keypoints_impl(pr, frames_dev, 1, det_all_dev, heat_dev, stream, 1, true);
 }
 
 int jh_predictor_stage_keypoints_gathered(jh_predictor* pr, const void* frames_dev, int frames_u8,
                                           const float* det_gathered_dev, int n_blocks, float* heat_dev,
                                           void* stream) {
   JH_REQUIRE(n_blocks >= 1, "block count");
-  return stage_keypoints_impl(pr, frames_dev, frames_u8 != 0, det_gathered_dev, heat_dev, stream, n_blocks);
+  return stage_keypoints_impl(pr, frames_dev, frames_u8 != 0, det_gathered_dev, heat_dev, stream, n_blocks, true);
 }
 
 int jh_predictor_stage_3d(jh_predictor* pr, const float* heat_all_dev, int t0, float* points_dev,
@@ -521,7 +533,7 @@ int jh_predictor_stage_3d(jh_predictor* pr, const float* heat_all_dev, int t0, f
   JH_REQUIRE(t0 >= 0 && t0 + pr->T3 <= pr->T, "frame range of the 3D stage");
   if (pr->run_3d(heat_all_dev, t0, nullptr, points_dev, conf_dev, s)) return 1;
   if (valid_dev)
-    JH_CHECK_HIP(hipMemcpyAsync(valid_dev, pr->valid + t0, (size_t)pr->T3 * sizeof(int),
+    JH_CHECK_HIP(hipMemcpyAsync(valid_dev, pr->valid_cur() + t0, (size_t)pr->T3 * sizeof(int),
                                 hipMemcpyDeviceToDevice, s));
   return 0;
 }
@@ -541,7 +553,7 @@ int jh_predictor_stage_3d_blocks(jh_predictor* pr, const float* heat_blocks_dev,
   if (pr->run_3d(heat_blocks_dev + (size_t)t_off * lay.frame_stride, t0, nullptr, points_dev, conf_dev, s,
                  &lay)) return 1;
   if (valid_dev)
-    JH_CHECK_HIP(hipMemcpyAsync(valid_dev, pr->valid + t0, (size_t)pr->T3 * sizeof(int),
+    JH_CHECK_HIP(hipMemcpyAsync(valid_dev, pr->valid_cur() + t0, (size_t)pr->T3 * sizeof(int),
                                 hipMemcpyDeviceToDevice, s));
   return 0;
 }
@@ -582,7 +594,7 @@ static int forward_graph(jh_predictor* pr, const void* frames_dev, int src_u8, f
   JH_CHECK_HIP(hipGraphLaunch(exec, s));
   const int n_pts = pr->T * pr->J * 3;
   hipLaunchKernelGGL(copy_out_kernel, dim3((n_pts + 255) / 256), dim3(256), 0, s, pr->g_points, pr->g_conf,
-                     pr->valid, points_dev, conf_dev, valid_dev, n_pts, pr->T * pr->J, pr->T);
+                     pr->valid_[0], points_dev, conf_dev, valid_dev, n_pts, pr->T * pr->J, pr->T);
   JH_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -592,6 +604,7 @@ static int forward_impl(jh_predictor* pr, const void* frames_dev, int src_u8, fl
   JH_REQUIRE(pr->Cloc == pr->C && pr->cfg.cam_lo == 0, "forward needs all cameras local");
   JH_REQUIRE(pr->T3 == pr->T, "forward needs time_batch_3d == time_batch");
   JH_REQUIRE(frames_dev && points_dev && conf_dev, "null frame / output pointer");
+  pr->slot = 0;                               // (the whole-path forward and its captured graph: centre set 0)
   // per-launch profiling needs the launches one by one; a caller that is itself capturing this
   // stream gets the plain launches too (its graph then holds them)
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -614,8 +627,8 @@ int jh_predictor_debug(jh_predictor* pr, float* center3d_f_dev, int32_t* center3
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t T = pr->T, C = pr->C;
   if (center3d_f_dev) JH_CHECK_HIP(hipMemcpyAsync(center3d_f_dev, pr->c3f, T * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
-  if (center3d_i_dev) JH_CHECK_HIP(hipMemcpyAsync(center3d_i_dev, pr->c3i, T * 3 * sizeof(int), hipMemcpyDeviceToDevice, s));
-  if (center_hm_dev) JH_CHECK_HIP(hipMemcpyAsync(center_hm_dev, pr->chm, T * C * 2 * sizeof(int), hipMemcpyDeviceToDevice, s));
+  if (center3d_i_dev) JH_CHECK_HIP(hipMemcpyAsync(center3d_i_dev, pr->c3i_cur(), T * 3 * sizeof(int), hipMemcpyDeviceToDevice, s));
+  if (center_hm_dev) JH_CHECK_HIP(hipMemcpyAsync(center_hm_dev, pr->chm_cur(), T * C * 2 * sizeof(int), hipMemcpyDeviceToDevice, s));
   if (det_dev) JH_CHECK_HIP(hipMemcpyAsync(det_dev, pr->det_all, T * C * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
   return 0;
 }
@@ -626,8 +639,8 @@ int jh_predictor_hybridnet_forward(jh_predictor* pr, const float* crops_dev,
                                    float* points_dev, float* conf_dev, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   JH_REQUIRE(pr->Cloc == pr->C && pr->T3 == pr->T, "hybridnet_forward needs all cameras local");
-  JH_CHECK_HIP(hipMemcpyAsync(pr->chm, center_hm_dev, (size_t)pr->T * pr->C * 2 * sizeof(int), hipMemcpyDeviceToDevice, s));
-  JH_CHECK_HIP(hipMemcpyAsync(pr->c3i, center3d_dev, (size_t)pr->T * 3 * sizeof(int), hipMemcpyDeviceToDevice, s));
+  JH_CHECK_HIP(hipMemcpyAsync(pr->chm_cur(), center_hm_dev, (size_t)pr->T * pr->C * 2 * sizeof(int), hipMemcpyDeviceToDevice, s));
+  JH_CHECK_HIP(hipMemcpyAsync(pr->c3i_cur(), center3d_dev, (size_t)pr->T * 3 * sizeof(int), hipMemcpyDeviceToDevice, s));
   if (launch_to_channel_last(crops_dev, pr->kp->input, s)) return 1;
   pr->kp->stem_src.mode = 0;                      // (the crops are given: the stem reads the plan's input)
   if (pr->kp->run(s)) return 1;

@@ -20,8 +20,12 @@ new design for the 8 x MI355X node:
   stage 3   reprojection + V2V + soft-argmax for the owned frames
   gather    (T/N, J, 4) results to every rank (tiny all-gather)
 
-submit() / flush() pipeline consecutive time batches so that the bulk exchange of one
-batch runs under the CenterDetect stage of the next; step() is submit() + flush().
+submit() / flush() pipeline consecutive time batches: the bulk exchange of batch i runs under the
+CenterDetect stage of batch i+1, and stage 3 of batch i runs on a SECOND HIP stream under stage 2
+(KeypointDetect) of batch i+1 -- the two share no buffer (the library keeps two sets of crop centres
+for exactly this: a stage-3 call reads the set of the stage-2 call that preceded it in host call
+order, include/jarvis_hip.h) and an event pair orders them against the exchanges; step() is
+submit() + flush().
 
 three_d='rank0' is the literal placement of BASELINE.json's north star / configs[3]:
 "RCCL all-gather of heatmaps, 3D stage on rank 0" -- the heatmaps of ALL frames are
@@ -106,6 +110,10 @@ class ShardedPredictor:
         self.res_all = torch.empty((n_res * self.T3 * self.J * 4,), **f32)
         self.valid_all = torch.empty((n_res * self.T3,), device=device, dtype=torch.int32)
         self._pending = None                     # exchange of the time batch in flight
+        # stage 3 (+ the result collectives) of batch i on its own stream, under stage 2 of batch i+1
+        self.cuda = torch.device(device).type == "cuda"
+        self.s3d = torch.cuda.Stream(device=device) if self.cuda else None
+        self._done3d = None                      # event: stage 3 of the last finished batch has read heat_recv
 
     def step(self, frames_local):
         """frames_local (T, Cloc, 3, H, W) -> points (T,J,3), conf (T,J), valid (T)."""
@@ -115,8 +123,8 @@ class ShardedPredictor:
     # ---- pipelined form: the bulk exchange of time batch i runs under the CenterDetect
     # stage of time batch i+1 (which touches neither the heatmap buffers nor the crop
     # centres the 3D stage of batch i still needs).  Order of one submit():
-    #     stage_center(i+1) || exchange(i)  ->  stage_3d(i)  ->  stage_keypoints(i+1)
-    #     -> exchange(i+1) started asynchronously
+    #     stage_center(i+1) || exchange(i)  ->  stage_3d(i) [second stream] || stage_keypoints(i+1)
+    #     -> exchange(i+1) started asynchronously once stage_3d(i) has let go of the receive buffer
     def submit(self, frames_local):
         """Start time batch i+1; returns the results of batch i (None on the first call)."""
         W = self.world
@@ -125,6 +133,11 @@ class ShardedPredictor:
         prev = self._finish()
         # det_gather is (W, T, Cl, 3): read in place, camera = source rank * Cl + local camera
         self.st.stage_keypoints_gathered(frames_local, self.det_gather, W, self.heat_local)
+        if self._done3d is not None:
+            # exchange(i+1) overwrites the receive buffer stage_3d(i) reads; the results returned above are
+            # stream-ordered for the caller from here on too
+            torch.cuda.current_stream().wait_event(self._done3d)
+            self._done3d = None
         if self.exchange == "alltoall":
             # block r of the send buffer = my cameras' heatmaps of rank r's frames
             self._pending = self.comm.all_to_all_single(self.heat_recv, self.heat_local,
@@ -136,13 +149,33 @@ class ShardedPredictor:
 
     def flush(self):
         """Results of the last submitted time batch (None if nothing is in flight)."""
-        return self._finish()
+        res = self._finish()
+        if self._done3d is not None:
+            torch.cuda.current_stream().wait_event(self._done3d)
+            self._done3d = None
+        return res
 
     def _finish(self):
+        """Stage 3 + result collectives of the batch in flight.  On a GPU they are issued on the second stream
+        (every rank issues its collectives in the same program order, whatever the stream); the caller's stream
+        picks the results up through the `_done3d` event."""
         if self._pending is None:
             return None
+        if not self.cuda:
+            return self._finish_on_current_stream()
+        cur = torch.cuda.current_stream()
+        self.s3d.wait_stream(cur)                # (result buffers of the previous batch have been cloned there)
+        with torch.cuda.stream(self.s3d):
+            res = self._finish_on_current_stream()
+            self._done3d = torch.cuda.Event()
+            self._done3d.record(self.s3d)
+        for t in res:
+            t.record_stream(cur)                 # allocated on the side stream, consumed on the caller's
+        return res
+
+    def _finish_on_current_stream(self):
         W = self.world
-        self._pending.wait()
+        self._pending.wait()                     # the current stream waits for exchange(i)
         self._pending = None
         if self.three_d == "rank0":
             if self.rank == 0:

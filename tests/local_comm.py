@@ -4,12 +4,17 @@ N emulated ranks (one Python thread each) can run the REAL distributed.py code p
 re-assembly and the pipelined submit/flush exactly as an N-GPU job would, with the data
 movement done by copies instead of RCCL.
 
-All ranks issue their GPU work on the same (default) stream, so device-side ordering equals
-host issue order; the two barriers of every collective make sure (1) all inputs have been
-produced (enqueued) before anybody copies and (2) all copies have been enqueued before any
-rank goes on to overwrite its input.
+The two barriers of every collective make sure (1) all inputs have been produced (enqueued) before
+anybody copies and (2) all copies have been enqueued before any rank goes on to overwrite its input.
+Ranks may issue their work on different HIP streams (ShardedPredictor runs stage 3 and the result
+collectives on a side stream): every rank therefore publishes an event recorded on ITS current stream
+with its input, consumers make their stream wait for it before copying, and after the copies every rank
+publishes a second event that the others' streams wait for before they go on -- the stream-level
+equivalent of the two host barriers.
 """
 import threading
+
+import torch
 
 
 class _Done:
@@ -22,6 +27,7 @@ class LocalWorld:
         self.world = world
         self.barrier = threading.Barrier(world)
         self.slots = [None] * world
+        self.done = [None] * world
 
     def comm(self, rank):
         return LocalComm(self, rank)
@@ -53,16 +59,38 @@ class LocalComm:
         self.w, self.rank = world, rank
 
     def _exchange(self, inp):
-        self.w.slots[self.rank] = inp
+        ev = None
+        if inp.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()                              # (on this rank's current stream: its input is complete here)
+        self.w.slots[self.rank] = (inp, ev)
         self.w.barrier.wait()
-        return list(self.w.slots)
+        ins = []
+        for t, e in self.w.slots:
+            if e is not None:
+                torch.cuda.current_stream().wait_event(e)
+            ins.append(t)
+        return ins
+
+    def _release(self, cuda):
+        """All copies enqueued (host barrier) AND executed before any rank's stream goes on."""
+        ev = None
+        if cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+        self.w.done[self.rank] = ev
+        self.w.barrier.wait()
+        for e in list(self.w.done):
+            if e is not None:
+                torch.cuda.current_stream().wait_event(e)
+        self.w.barrier.wait()                        # (nobody overwrites `done` before everybody has read it)
 
     def all_gather_into_tensor(self, out, inp, group=None, async_op=False):
         ins = self._exchange(inp)
         chunks = out.view((self.w.world,) + tuple(inp.shape))
         for r, t in enumerate(ins):
             chunks[r].copy_(t)
-        self.w.barrier.wait()
+        self._release(inp.is_cuda)
         return _Done()
 
     def all_to_all_single(self, out, inp, group=None, async_op=False):
@@ -72,12 +100,12 @@ class LocalComm:
         blocks = out.view((self.w.world, n) + tuple(inp.shape[1:]))
         for r, t in enumerate(ins):
             blocks[r].copy_(t.view((self.w.world, n) + tuple(inp.shape[1:]))[self.rank])
-        self.w.barrier.wait()
+        self._release(inp.is_cuda)
         return _Done()
 
     def broadcast(self, tensor, src, group=None, async_op=False):
         ins = self._exchange(tensor)
         if self.rank != src:
             tensor.copy_(ins[src])
-        self.w.barrier.wait()
+        self._release(tensor.is_cuda)
         return _Done()
