@@ -63,7 +63,7 @@ CONFIGS = {
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_16x16x32_bf16 / 32x32x16, dense
 PEAK_HBM_GBS = 8000.0
-PMC_TRAFFIC = os.path.join("profiles", "r03_pmc_traffic.json")
+PMC_TRAFFIC = os.path.join("profiles", "r04_pmc_traffic.json")
 
 
 def usable_cores():
@@ -77,6 +77,15 @@ def usable_cores():
     except (OSError, ValueError):
         pass
     return n
+
+
+def kernel_family(name):
+    """Which roofline bounds a profiled launch, by kernel FAMILY (not by name prefix): the MFMA convolutions
+    (`conv_mfma_kernel`, the Winograd / bf16x3 / fused ConvTranspose kernels -- all named conv{2,3}d_*) are priced
+    against the matrix-core peak of their arithmetic type; everything else -- the vector-ALU stem (`stem_conv_*`:
+    HBM-bound on the frame rows it fetches), the one-channel CenterDetect head (`deconv_*_c1`), fused BiFPN nodes,
+    InstanceNorm passes, depthwise convolutions, the reprojection gather, argmax / soft-argmax -- against HBM."""
+    return "mfma" if name.startswith(("conv2d_", "conv3d_")) else "hbm"
 
 
 def executed_flops(name, flops):
@@ -111,7 +120,7 @@ def kernel_table(recs, passes, top=10):
     out = []
     for name, r in sorted(rows.items(), key=lambda kv: -kv[1]["ms"]):
         s = r["ms"] * 1e-3
-        if r["flops"] > 0 and name.startswith("conv"):
+        if r["flops"] > 0 and kernel_family(name) == "mfma":
             ex = executed_flops(name, r["flops"])
             peak = PEAK_BF16_MFMA_TFLOPS if "bf16x3" in name else PEAK_F32_MFMA_TFLOPS
             row = dict(kernel=name, bound="mfma", achieved=ex / s / 1e12, peak=peak,
@@ -123,7 +132,10 @@ def kernel_table(recs, passes, top=10):
                    share_of_step=r["ms"] / total, algorithmic_flops_per_launch=r["flops"] / r["n"],
                    algorithmic_bytes_per_launch=r["bytes"] / r["n"])
         out.append(row)
-    return out[:top], total
+    # executed matrix-core FLOPs of the whole pass (all MFMA launches, not only the top rows)
+    ex_total = sum(executed_flops(n, r["flops"]) for n, r in rows.items()
+                   if r["flops"] > 0 and kernel_family(n) == "mfma")
+    return out[:top], total, ex_total
 
 
 def percentiles(ms):
@@ -225,7 +237,11 @@ def main():
         os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/jh_rccl_%h_%p.log")   # the JSON line is last
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:
-            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+            import socket
+            with socket.socket() as sk:                   # a free port (two benches on one box must not collide)
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
         import datetime
         dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=300))
 
@@ -420,7 +436,7 @@ def main():
         recs = []
         for _ in range(P):
             recs += N.profile(prof_fn)
-        table, total_ms = kernel_table(recs, P, int(os.environ.get("JH_BENCH_TOP", "10")))
+        table, total_ms, ex_flops = kernel_table(recs, P, int(os.environ.get("JH_BENCH_TOP", "10")))
         top = table[0]
         T_prof = T // gs if sharded else T
         roof = {k: top[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms",
@@ -463,6 +479,17 @@ def main():
                             if k not in ("algorithmic_flops_per_launch", "algorithmic_bytes_per_launch")}
                            for row in table]
         line["kernel_time_ms_per_time_batch"] = total_ms
+        if not sharded:
+            # the whole step against the matrix-core peak: FLOPs the MFMA kernels execute per step (K time batches)
+            # over the step's wall time -- what the non-MFMA kernels, stalls and launch gaps leave of the peak
+            e2e = ex_flops * K / (dt / args.steps) / 1e12
+            line["roofline_end_to_end"] = {
+                "bound": "mfma", "achieved": e2e, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": e2e / PEAK_F32_MFMA_TFLOPS,
+                "executed_gflop_per_frame": ex_flops / T / 1e9,
+                "algorithmic_gflop_per_frame": sum(r[2] for r in recs[:len(recs) // P]) / T / 1e9,
+                "note": "executed matrix-core FLOPs of one step (channel padding included, Winograd at 12/27 of the "
+                        "direct count) / ms_per_step; the remainder is HBM-bound kernels, stalls and launch gaps"}
 
     if rank == 0 and not sharded and not args.no_uint8:
         # ---- the same step fed uint8 BGR frames as the decoder delivers
@@ -634,7 +661,7 @@ def main():
             torch.cuda.synchronize()
             rdt = time.perf_counter() - t0
             N.profile(lambda: rp.preds[0].forward(fr, routs[0]))
-            rtab, _ = kernel_table(N.profile(lambda: rp.preds[0].forward(fr, routs[0])), 1, 200)
+            rtab, _, _ = kernel_table(N.profile(lambda: rp.preds[0].forward(fr, routs[0])), 1, 200)
             rk = [r for r in rtab if "bf16x3" in r["kernel"]]
             red = {"mode": "bf16x3", "value": T * K * nst / rdt, "unit": "multi-view frames/s",
                    "ms_per_step": 1e3 * rdt / nst, "steps": nst,

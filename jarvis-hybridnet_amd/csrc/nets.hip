@@ -419,6 +419,10 @@ int EffTrackPlan::node(const ParamMap& pm, const std::string& cp, int n_in, cons
   return 0;
 }
 
+void EffTrackPlan::set_stem_traffic(double bytes) {
+  if (stem_op_ >= 0 && stem_op_ < (int)ops_.size()) ops_[stem_op_].bytes = bytes;
+}
+
 // EfficientTrackBackbone.forward, model.py:114-130 (res2 branch only: the
 // final_conv1 branch is dead on the inference path, model.py:57-58 / jarvis3D.py:147)
 int EffTrackPlan::build(const ParamMap& pm, const std::string& pre, int size, int joints, int N,
@@ -450,7 +454,10 @@ int EffTrackPlan::build(const ParamMap& pm, const std::string& pre, int size, in
     st = scratch((size_t)N * 16 * kStatW);
     const Act xin = input, xo = x.a;
     const double opix = (double)N * xo.pixels();
-    push("conv2d_k3s2_3x16@" + std::to_string(xo.W), 2.0 * opix * 27 * 16,
+    // (named by FAMILY: this layer runs on the vector ALUs and is HBM-bound on the frame rows it fetches; its
+    //  algorithmic bytes depend on what feeds it -- set_stem_traffic() -- so bench.py prices it against HBM)
+    stem_op_ = (int)ops_.size();
+    push("stem_conv_k3s2_3x16@" + std::to_string(xo.W), 2.0 * opix * 27 * 16,
          4.0 * ((double)N * xin.pixels() * 3 + opix * 16 + 27 * 16),
          [this, xin, xo, wd, st](hipStream_t s) {
            if (stem_src.mode) return launch_stem_conv_src(stem_src, xin, wd, xo, sc(st), s);

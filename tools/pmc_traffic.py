@@ -18,13 +18,24 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "jarvis-hybridnet_amd", "csrc")
 
-# bench kernel name -> (SQL LIKE pattern of the device function, which (grid, lds) group)
+# bench kernel name -> list of (SQL LIKE pattern of the device function, which launch group of that function).
+# A bench name that covers several device functions / shapes (all InstanceNorm passes, both fused stems, the two
+# node forms of a level) gets the dispatch-weighted AVERAGE per launch over its parts.
 SPECS = {
-    "conv3d_k3s1wino_46x46@32": ("%conv3d_wino_pw_kernel%", "most_dispatches"),
-    "conv3d_k3s1wino_92x92@16": ("%conv3d_wino_pw_kernel%", "fewest_dispatches"),
-    "reproject_gather": ("%repro_cube_kernel%", "largest_grid"),
-    "bifpn_node_56x56@64": ("%bifpn_rows_kernel<2,%", "largest_grid"),
-    "preprocess_resize": ("%preprocess_resize%", "largest_grid"),
+    "conv3d_k3s1wino_46x46@32": [("%conv3d_wino_pw_kernel%", "most_dispatches")],
+    "conv3d_k3s1wino_92x92@16": [("%conv3d_wino_pw_kernel%", "fewest_dispatches")],
+    "reproject_gather": [("%repro_cube_kernel%", "largest_grid")],
+    "bifpn_node_56x56@64": [("%bifpn_rows_kernel<56, 2, 1, 0, 2, true>%", "largest_grid")],
+    "bifpn_node_56x64@64": [("%bifpn_rows_kernel<56, 3, 1, 2, 0, false>%", "largest_grid")],
+    "bifpn_node_56x56@32": [("%bifpn_rows_kernel<56, 2, 1, 0, 2, false>%", "largest_grid"),
+                            ("%bifpn_rows_kernel<56, 3, 0, 0, 2, false>%", "largest_grid")],
+    "norm_apply": [("%norm_apply_kernel%", "all")],
+    "conv2d_k4s2T_64x23@128": [("%deconv4_fused_kernel%", "largest_grid")],
+    "stem_conv_k3s2_3x16@128": [("%stem_conv_kernel<1,%", "largest_grid"), ("%stem_conv_kernel<2,%", "largest_grid")],
+    "conv3d_k3s2_23x46@32": [("%conv_mfma_kernel<3, 3, 2,%", "largest_grid")],
+    "conv2d_k3s1_16x16@128": [("%conv_mfma_kernel<2, 3, 1, 1, 16, 16, 1, 2>%", "largest_grid")],
+    "conv2d_k5s2_16x96@32": [("%conv_mfma_kernel<2, 5, 2,%", "largest_grid")],
+    "deconv_k4s2T_c1": [("%deconv_c1_kernel%", "largest_grid")],
 }
 
 
@@ -39,6 +50,8 @@ def csrc_sha256():
 
 
 def groups(db_path, pattern, counter):
+    """(function, workgroups, lds, avg counter, dispatches, avg duration) per launch group of the functions that
+    match `pattern`."""
     db = sqlite3.connect(db_path)
     return db.execute(
         "select p.name, k.grid_x / k.workgroup_x, k.lds_size, avg(p.counter_value), count(*), avg(p.duration) "
@@ -48,36 +61,46 @@ def groups(db_path, pattern, counter):
 
 
 def pick(rows, rule):
+    """The launch group(s) a rule selects: a list of rows."""
     if not rows:
-        return None
+        return []
+    if rule == "all":
+        return sorted(rows, key=lambda r: (r[0], r[1], r[2]))
     if rule == "most_dispatches":
-        return max(rows, key=lambda r: r[4])
+        return [max(rows, key=lambda r: r[4])]
     if rule == "fewest_dispatches":
-        return min(rows, key=lambda r: r[4])
-    return max(rows, key=lambda r: r[1])
+        return [min(rows, key=lambda r: r[4])]
+    return [max(rows, key=lambda r: r[1])]
 
 
 def main(fetch_db, write_db, time_batch, out, command):
     res = {"_comment": "HBM-side bytes per launch from rocprofv3 PMC passes (separate --pmc FETCH_SIZE and --pmc "
                        "WRITE_SIZE runs of the command below; counters in KiB; FETCH_SIZE doubled as "
-                       "MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950). Written by "
+                       "MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950). A bench name that covers "
+                       "several device functions / shapes carries the dispatch-weighted average per launch. Written by "
                        "tools/pmc_traffic.py.",
            "command": command, "time_batch": int(time_batch), "csrc_sha256": csrc_sha256()}
-    for bench_name, (pattern, rule) in SPECS.items():
-        f = pick(groups(fetch_db, pattern, "FETCH_SIZE"), rule)
-        w = pick(groups(write_db, pattern, "WRITE_SIZE"), rule)
-        if f is None or w is None:
-            print("pmc_traffic: no dispatches match %s" % pattern, file=sys.stderr)
+    for bench_name, parts in SPECS.items():
+        f, w = [], []
+        for pattern, rule in parts:
+            f += pick(groups(fetch_db, pattern, "FETCH_SIZE"), rule)
+            w += pick(groups(write_db, pattern, "WRITE_SIZE"), rule)
+        if not f or not w:
+            print("pmc_traffic: no dispatches match %s" % bench_name, file=sys.stderr)
             continue
-        if (f[1], f[2]) != (w[1], w[2]):
-            print("pmc_traffic: %s: fetch / write passes picked different launch groups %s vs %s" %
-                  (bench_name, f[1:3], w[1:3]), file=sys.stderr)
+        if [(r[0], r[1], r[2]) for r in f] != [(r[0], r[1], r[2]) for r in w]:
+            print("pmc_traffic: %s: fetch / write passes picked different launch groups" % bench_name, file=sys.stderr)
             continue
+        nf, nw = sum(r[4] for r in f), sum(r[4] for r in w)
+        fetch = sum(r[3] * r[4] for r in f) / nf
+        write = sum(r[3] * r[4] for r in w) / nw
         res[bench_name] = {
-            "kernel": "%s (blocks %d, lds %d)" % (f[0][:80], f[1], f[2] or 0),
-            "dispatches_per_pass": [f[4], w[4]], "avg_us": [f[5] / 1e3, w[5] / 1e3],
-            "fetch_size_kib": f[3], "write_size_kib": w[3],
-            "hbm_bytes_per_launch": (2.0 * f[3] + w[3]) * 1024.0,
+            "kernel": "; ".join("%s (blocks %d, lds %d)" % (r[0][:80], r[1], r[2] or 0) for r in f[:4]) +
+                      (" ... %d launch groups" % len(f) if len(f) > 4 else ""),
+            "dispatches_per_pass": [nf, nw],
+            "avg_us": [sum(r[5] * r[4] for r in f) / nf / 1e3, sum(r[5] * r[4] for r in w) / nw / 1e3],
+            "fetch_size_kib": fetch, "write_size_kib": write,
+            "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
         }
     with open(out, "w") as fh:
         json.dump(res, fh, indent=1)

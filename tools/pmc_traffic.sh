@@ -3,9 +3,9 @@
 # WRITE_SIZE; counters in their own runs, program directly after `--`) over the bench command at
 # the benched time batch, summarised into profiles/<round>_pmc_traffic.json with the SHA-256 of
 # csrc/ (bench.py reports `traffic` only for a matching tree).  Run on the GPU box:
-#   tools/pmc_traffic.sh r03
+#   tools/pmc_traffic.sh r04
 set -e
-round=${1:-r03}
+round=${1:-r04}
 root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$root"
 T=32
