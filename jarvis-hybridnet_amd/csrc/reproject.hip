@@ -358,6 +358,15 @@ __global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
     x = fmaxf(x, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xF, 0xF, true)));
     return fmaxf(x, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x141, 0xF, 0xF, true)));
   };
+  // (the tables of cameras 0 and 1 are requested BEFORE the boxes are computed -- their round trip then runs under
+  //  the boxes' own loads and arithmetic instead of after them: two dependent round trips in the prologue, not three)
+  float2 tpre[2][TPT];
+#pragma unroll
+  for (int e = 0; e < TPT; ++e)
+    if (e * NT + tid < NTAB) {
+      tpre[0][e] = a.coarse[(size_t)(t * C) * nvox_c + ctab_src[e]];
+      if (C > 1) tpre[1][e] = a.coarse[(size_t)(t * C + 1) * nvox_c + ctab_src[e]];
+    }
   // ---- boxes of ALL cameras, once per cube (prologue; wave w takes cameras w, w + waves, ...): lane
   // n & 7 interpolates the cube's n-th corner VOXEL from the coarse field in global memory (the field is
   // piecewise trilinear and the projection monotone along lines: the extremes of (u, v) over the cube
@@ -452,7 +461,6 @@ __global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
           o = (int)0x80000000 | ((hy * Hh + hx) * JPB);
       }
       off[v] = o;
-      __builtin_amdgcn_sched_barrier(0);                 // one voxel at a time: register pressure
     }
   };
   // patch of camera c -> LDS buffer c & 1.  LDS slot s (16 bytes) of a patch row = quad s % SPX of staged pixel
@@ -497,8 +505,8 @@ __global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
 #pragma unroll
   for (int e = 0; e < TPT; ++e)
     if (e * NT + tid < NTAB) {
-      ctab[e * NT + tid] = a.coarse[(size_t)(t * C) * nvox_c + ctab_src[e]];
-      if (C > 1) ctab[NTAB + e * NT + tid] = a.coarse[(size_t)(t * C + 1) * nvox_c + ctab_src[e]];
+      ctab[e * NT + tid] = tpre[0][e];
+      if (C > 1) ctab[NTAB + e * NT + tid] = tpre[1][e];
     }
   __syncthreads();
   Geo gc = geometry(box(0));
@@ -543,7 +551,6 @@ __global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
       for (int q = 0; q < Q; ++q) {
         acc[v][q].x += h[q][0]; acc[v][q].y += h[q][1]; acc[v][q].z += h[q][2]; acc[v][q].w += h[q][3];
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
     // taps that are not in LDS (a box over the LDS budget; never seen otherwise): from global memory.
     // Those lanes added the zero pixel above, so the camera order of the sum is unchanged.
