@@ -123,20 +123,23 @@ __global__ __launch_bounds__(512) void conv3d_wino_pw_kernel(const WinoArgs a, i
     // goes into the base address of a buffer descriptor (scalar work), the channel pass into the
     // scalar offset of the load.  Pixels outside the volume (the convolution's zero padding)
     // get bit 31 set in their offset: beyond num_records, the buffer load returns 0 without
-    // touching memory.  Volume extents are multiples of the tile (checked by the host), so a
-    // pixel is outside exactly when it lies in the first / last patch plane of a border tile:
-    // six constant lane masks, six scalar flags per tile.
+    // touching memory.  A pixel is outside exactly when it lies in the first patch plane of a
+    // first tile, or past the volume's last plane in a last tile -- patch plane index > r, with r the
+    // extent of the volume inside its last tile (the tile size when the extent is a multiple of it:
+    // then only the last patch plane; round 4: any remainder, e.g. the 36^3 / 18^3 volumes of the
+    // reference's shipped 72^3 grid): six constant lane masks, six scalar flags per tile.
     int prel[ITER];
     unsigned mz0 = 0, mz1 = 0, my0 = 0, my1 = 0, mx0 = 0, mx1 = 0, mtail = 0;
+    const int rz = a.D % kPTZ ? a.D % kPTZ : kPTZ, ry = a.H % kWTY ? a.H % kWTY : kWTY, rx = a.W % kWTX ? a.W % kWTX : kWTX;
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
       const int idx = lane + it * 64;
       const int pix = idx >> 1;
       const int px = pix % kWPX, py = (pix / kWPX) % kWPY, pz = pix / (kWPX * kWPY);
       prel[it] = (((pz * a.H + py) * a.W + px) * a.cin_p + q * 4) * 4;
-      mz0 |= (pz == 0) << it; mz1 |= (pz == kPPZ - 1) << it;
-      my0 |= (py == 0) << it; my1 |= (py == kWPY - 1) << it;
-      mx0 |= (px == 0) << it; mx1 |= (px == kWPX - 1) << it;
+      mz0 |= (pz == 0) << it; mz1 |= (pz > rz) << it;
+      my0 |= (py == 0) << it; my1 |= (py > ry) << it;
+      mx0 |= (px == 0) << it; mx1 |= (px > rx) << it;
       mtail |= (idx >= kPNP * 2) << it;                     // (beyond the patch: never valid)
     }
     int pvo[ITER];                                          // byte offsets of the patch to request
@@ -619,7 +622,6 @@ int launch_conv3d_wino_pw(const WinoArgs& a, int nr, hipStream_t s) {
   const int groups = (nb + nr - 1) / nr;
   const long total = (long)tiles_sp * groups * a.N;
   if (a.cin_p < 24 || total < 2L * cus || total > (1L << 30)) return -1;       // P >= 3
-  if (a.D % kPTZ || a.H % kWTY || a.W % kWTX) return -1;                       // (border masks of the loader)
   if ((long)a.D * a.H * a.W * a.cin_p * 4 + (long)(a.H + 1) * a.W * a.cin_p * 4 + 64 >= (1L << 31)) return -1;
   JH_REQUIRE((size_t)4 * kPTZ * nr * 64 * 4 <= (size_t)kPVSZ, "wino (persistent) dump buffer");
   const size_t lds = (size_t)(2 * kPRS + 2 * kPVSZ + 4 * nr * 16 * 2 + 2 * a.cin_p) * sizeof(float);

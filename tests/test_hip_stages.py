@@ -235,15 +235,18 @@ def test_submodule_path_graph_capture(golden):
     assert (captured[1].cpu() - torch.from_numpy(g["c4.reconstruct"])).abs().max() < 1e-3
 
 
-def test_v2v_time_batch_runs_persistent_kernel(monkeypatch):
+@pytest.mark.parametrize("G", [64, 72])
+def test_v2v_time_batch_runs_persistent_kernel(G, monkeypatch):
     """V2VNet on a time batch of 5 volumes (64^3, J = 23): 640 output tiles per Res3DBlock conv,
     which is where the persistent wave-specialised Winograd kernel (csrc/conv3d_wino_pw.hip) takes
     over from the one-role kernel (T = 1 falls back to it).  Covers its InstanceNorm(+ReLU)-on-load
-    commit path, the fused statistics and unequal per-workgroup tile lists, against the oracle."""
+    commit path, the fused statistics and unequal per-workgroup tile lists, against the oracle.
+    G = 72 (the reference's shipped grid): 36^3 and 18^3 volumes, whose last tiles along every axis are
+    partial (36 = 4.5 x 8, 18 = 4.5 x 4 = 2.25 x 8): the loader's border masks for any remainder."""
     from jarvis_hybridnet_amd import synthetic as S
     from jarvis_hybridnet_amd.hybridnet.v2vnet import V2VNet
     from oracle import hybridnet_oracle as O
-    J, G, T = 23, 64, 5
+    J, T = 23, 5
     sd = S.v2v_weights(J, 22)
     x = torch.cat([cases.v2v_input(J, G, 30 + t) for t in range(T)])
     with torch.no_grad():
