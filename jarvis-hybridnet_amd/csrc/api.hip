@@ -450,7 +450,8 @@ static int stage_center_impl(jh_predictor* pr, const void* frames_dev, int src_u
     for (int i = 0; i < 3; ++i) { src.mean[i] = pr->cfg.mean[i]; src.stdv[i] = pr->cfg.std[i]; }
     // algorithmic bytes of the fused launch: the four bilinear taps of every network-input pixel (3 channels,
     // 1 or 4 bytes each) + the stem's 16-channel output at half resolution (16 B per input pixel)
-    pr->center->set_stem_traffic((double)N * S * S * (12.0 * (src_u8 ? 1 : 4) + 16.0));
+    // (stem output: 16 or 32 channels at half resolution = 16 or 32 B per input pixel)
+    pr->center->set_stem_traffic((double)N * S * S * (12.0 * (src_u8 ? 1 : 4) + pr->center->stem_channels()));
   } else {
     JH_PROF("preprocess_resize", 0.0, (double)N * S * S * (12.0 * (src_u8 ? 1 : 4) + 3 * 4),
             launch_preprocess_resize(frames_dev, src_u8, pr->center->input.p, N, pr->cfg.img_h,
@@ -502,7 +503,7 @@ static int stage_keypoints_impl(jh_predictor* pr, const void* frames_dev, int sr
     src.center_hm = pr->chm_cur(); src.Cloc = pr->Cloc; src.C = pr->C; src.cam0 = c.cam_lo;
     src.H = c.img_h; src.W = c.img_w;
     for (int i = 0; i < 3; ++i) { src.mean[i] = c.mean[i]; src.stdv[i] = c.std[i]; }
-    pr->kp->set_stem_traffic((double)pr->T * pr->Cloc * pr->B * pr->B * (3.0 * (src_u8 ? 1 : 4) + 16.0));
+    pr->kp->set_stem_traffic((double)pr->T * pr->Cloc * pr->B * pr->B * (3.0 * (src_u8 ? 1 : 4) + pr->kp->stem_channels()));
   } else {
     JH_PROF("preprocess_crop", 0.0, (double)pr->T * pr->Cloc * pr->B * pr->B * (src_u8 ? 15.0 : 24.0),
             launch_preprocess_crop(frames_dev, src_u8, pr->chm_cur(), pr->kp->input.p, pr->T, pr->Cloc, pr->C,

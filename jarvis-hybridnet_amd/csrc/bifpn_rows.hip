@@ -361,7 +361,9 @@ void bifpn_rows_kernel(const NodeArgs a, int seg_rows, int strips) {
 bool bifpn_rows_eligible(const NodeArgs& a) {
   if (JH_ENV_KNOB("JH_NODE_ROWS") == 0 || a.rows == 0) return false;
   if (a.Cp != 56 && !(a.Cp == 88 && JH_ENV_KNOB("JH_NODE_ROWS88") != 0)) return false;
-  if (a.cout_p16 != (a.Cp + 15) / 16 * 16 || a.W % 16 != 0 || a.W < 32 || a.H < 16) return false;
+  // (88 channels: also the 16-pixel-wide level -- one strip per image -- because the tile kernel's path for more than
+  //  64 channels is slow there, 0.10 ms per launch against 0.05; at 56 channels the tile kernel wins below 32 pixels)
+  if (a.cout_p16 != (a.Cp + 15) / 16 * 16 || a.W % 16 != 0 || a.W < (a.Cp == 88 ? 16 : 32) || a.H < 16) return false;
   if (a.mode[0] != FUSE_SAME) return false;
   if (a.rows < 0) {
     // (one wave per workgroup walking >= 10 rows: below ~2048 strips the chip is not filled and the tile form wins)

@@ -318,7 +318,7 @@ int launch_conv_bf16x3(const ConvDesc& d, const ConvWeights& w, const Act& x, co
 int precision_mode();
 void set_precision_mode(int m);
 // vector-ALU stem convolution 3 -> 16, k3 s2 p1 (csrc/stem.hip)
-void pack_stem_weights(const float* w_host, float* packed);
+void pack_stem_weights(const float* w_host, float* packed, int cout);
 int launch_stem_conv(const Act& x, const float* w_dev, const Act& y, double* stats, hipStream_t s);
 struct StemSource;
 int launch_stem_conv_src(const StemSource& src, const Act& x, const float* w_dev, const Act& y, double* stats,

@@ -107,6 +107,7 @@ class EffTrackPlan : public Plan {
   StemSource stem_src;
   // algorithmic bytes of the (fused) stem launch for the profiler: taps read from the frames + stem output
   void set_stem_traffic(double bytes);
+  int stem_channels() const { return stem_ch_; }
   // Which form the high-resolution BiFPN nodes take (NodeArgs::rows), set before build().  A predictor sets it
   // from its time batch ALONE (not from the number of cameras it owns), so that a camera-sharded rank and the
   // single-GPU run of the same time batch launch the same kernels and stay bit-equal; -1: by the
@@ -116,7 +117,7 @@ class EffTrackPlan : public Plan {
   Act heat;      // [N][H/2][W/2][Jp]  res2 (ConvTranspose output)
   Act res1;      // [N][H/4][W/4][Jp]  final_conv1 output (only with want_res1)
   int J = 0;
-  int stem_op_ = -1;
+  int stem_op_ = -1, stem_ch_ = 16;
 
  private:
   int mbconv(const ParamMap& pm, const std::string& p, int stage, int k, int stride, int cin,

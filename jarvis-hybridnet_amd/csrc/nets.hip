@@ -442,23 +442,24 @@ int EffTrackPlan::build(const ParamMap& pm, const std::string& pre, int size, in
   if (new_act(N, 1, H / 2, W / 2, stem, &x.a)) return 1;
   size_t st = 0;
   const std::string bb = pre + "backbone_net.model.";
-  if (stem == 16 && JH_ENV_KNOB("JH_STEM_MFMA") <= 0) {
-    // the small model's 3 -> 16 stem runs on the vector ALUs (csrc/stem.hip): K = 27 is too
-    // little matrix work per workgroup for the MFMA kernel
+  if ((stem == 16 || stem == 32) && JH_ENV_KNOB("JH_STEM_MFMA") <= 0) {
+    // the 3 -> 16 (small) / 3 -> 32 (medium, large) stem runs on the vector ALUs (csrc/stem.hip): K = 27 is
+    // too little matrix work per workgroup for the MFMA kernel, and the pre-processing fuses into it
     const float* wh = nullptr;
-    if (get(pm, bb + "_conv_stem.weight", (size_t)16 * 27, &wh)) return 1;
-    std::vector<float> packed(27 * 16);
-    pack_stem_weights(wh, packed.data());
+    if (get(pm, bb + "_conv_stem.weight", (size_t)stem * 27, &wh)) return 1;
+    std::vector<float> packed(27 * stem);
+    pack_stem_weights(wh, packed.data(), stem);
     float* wd = nullptr;
     if (upload(packed, &wd)) return 1;
-    st = scratch((size_t)N * 16 * kStatW);
+    st = scratch((size_t)N * stem * kStatW);
     const Act xin = input, xo = x.a;
     const double opix = (double)N * xo.pixels();
     // (named by FAMILY: this layer runs on the vector ALUs and is HBM-bound on the frame rows it fetches; its
     //  algorithmic bytes depend on what feeds it -- set_stem_traffic() -- so bench.py prices it against HBM)
     stem_op_ = (int)ops_.size();
-    push("stem_conv_k3s2_3x16@" + std::to_string(xo.W), 2.0 * opix * 27 * 16,
-         4.0 * ((double)N * xin.pixels() * 3 + opix * 16 + 27 * 16),
+    stem_ch_ = stem;
+    push("stem_conv_k3s2_3x" + std::to_string(stem) + "@" + std::to_string(xo.W), 2.0 * opix * 27 * stem,
+         4.0 * ((double)N * xin.pixels() * 3 + opix * stem + 27 * stem),
          [this, xin, xo, wd, st](hipStream_t s) {
            if (stem_src.mode) return launch_stem_conv_src(stem_src, xin, wd, xo, sc(st), s);
            return launch_stem_conv(xin, wd, xo, sc(st), s);

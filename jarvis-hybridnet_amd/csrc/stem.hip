@@ -1,6 +1,7 @@
 // Stem convolution of the EfficientNet trunk on the vector ALUs:
-// Conv2d(3 -> 16, k3, s2, p1, bias=False)  (jarvis/efficienttrack/efficientnet.py:150-152,
-// model.py:536-538; 16 = the `small` model's round_filters(32, 0.5)).
+// Conv2d(3 -> CO, k3, s2, p1, bias=False)  (jarvis/efficienttrack/efficientnet.py:150-152,
+// model.py:536-538; CO = 16 for the `small` model -- round_filters(32, 0.5) --, 32 for `medium` and `large`:
+// round 4, so that the reference's default model size gets the fused pre-processing too).
 //
 // On the MFMA path the 3 input channels are padded to 8 (K = 72 for 27 real taps) and every
 // workgroup spends several hundred staging / epilogue instructions on 36 MFMAs: 16 TFLOP/s, a
@@ -39,16 +40,17 @@ struct StemSrcArgs {           // MODE != 0: the frames this launch pre-processe
   float3 mean, stdv;
 };
 
-template <int MODE, int SRC>
+template <int MODE, int SRC, int CO = 16>
 __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ x,
-                                                        const float* __restrict__ w /* [9][3][16] */,
+                                                        const float* __restrict__ w /* [9][3][CO] */,
                                                         float* __restrict__ y, double* __restrict__ stats,
                                                         int H, int W, StemSrcArgs sa) {
+  static_assert(CO == 16 || CO == 32, "stem output channels");
   // (the statistics scratch lies over the patch, which is dead once every thread has its 16 sums: 19.5 instead of
   //  35.8 KB of LDS = twice the workgroups per CU; the kernel is bound by the latency of its patch loads)
-  __shared__ __attribute__((aligned(16))) float4 patch[kStP * kStP > 16 * 64 ? kStP * kStP : 16 * 64];
+  __shared__ __attribute__((aligned(16))) float4 patch[kStP * kStP > CO * 64 ? kStP * kStP : CO * 64];
   float* red = reinterpret_cast<float*>(patch);      // statistics: [channel][thread]
-  __shared__ float red2[2 * 16 * 16];
+  __shared__ float red2[2 * CO * 16];
   const int tid = threadIdx.x;
   const int Ho = H >> 1, Wo = W >> 1;
   const int tiles_x = (Wo + kStT - 1) / kStT;
@@ -87,9 +89,9 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
   }
   __syncthreads();
   const int ty = tid >> 4, tx = tid & 15;
-  sf2 acc[8];
+  sf2 acc[CO / 2];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = (sf2){0.f, 0.f};
+  for (int i = 0; i < CO / 2; ++i) acc[i] = (sf2){0.f, 0.f};
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -100,10 +102,10 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
       for (int ci = 0; ci < 3; ++ci) {
         // (uniform address: the weights come through the scalar cache into SGPRs, not as 108 LDS
         //  broadcast reads per thread -- the kernel was LDS-bandwidth-bound on them)
-        const float4* wq = reinterpret_cast<const float4*>(w + ((ky * 3 + kx) * 3 + ci) * 16);
+        const float4* wq = reinterpret_cast<const float4*>(w + ((ky * 3 + kx) * 3 + ci) * CO);
         const sf2 xv = (sf2){iv[ci], iv[ci]};
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
+        for (int q4 = 0; q4 < CO / 4; ++q4) {
           const float4 wv = wq[q4];
           acc[q4 * 2 + 0] = __builtin_elementwise_fma(xv, (sf2){wv.x, wv.y}, acc[q4 * 2 + 0]);
           acc[q4 * 2 + 1] = __builtin_elementwise_fma(xv, (sf2){wv.z, wv.w}, acc[q4 * 2 + 1]);
@@ -113,9 +115,9 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
   const int oy = oy0 + ty, ox = ox0 + tx;
   const bool in_img = oy < Ho && ox < Wo;
   if (in_img) {
-    float4* dst = reinterpret_cast<float4*>(y + (((size_t)n * Ho + oy) * Wo + ox) * 16);
+    float4* dst = reinterpret_cast<float4*>(y + (((size_t)n * Ho + oy) * Wo + ox) * CO);
 #pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4)
+    for (int q4 = 0; q4 < CO / 4; ++q4)
       dst[q4] = make_float4(acc[q4 * 2][0], acc[q4 * 2][1], acc[q4 * 2 + 1][0], acc[q4 * 2 + 1][1]);
   }
   if (stats) {
@@ -123,10 +125,11 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
     // add 16 values each, then one thread per channel adds the 16 partials: a fixed order
     __syncthreads();                                 // (everyone is done reading the patch)
 #pragma unroll
-    for (int c = 0; c < 16; ++c) red[c * 256 + tid] = in_img ? acc[c >> 1][c & 1] : 0.f;
+    for (int c = 0; c < CO; ++c) red[c * 256 + tid] = in_img ? acc[c >> 1][c & 1] : 0.f;
     __syncthreads();
-    {
-      const int c = tid >> 4, part = tid & 15;
+#pragma unroll
+    for (int cg = 0; cg < CO / 16; ++cg) {             // (16 channels x 16 parts per round of the 256 threads)
+      const int c = cg * 16 + (tid >> 4), part = tid & 15;
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -138,32 +141,36 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
       red2[(c * 16 + part) * 2 + 1] = s2;
     }
     __syncthreads();
-    if (tid < 16) {
+    if (tid < CO) {
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         s1 += red2[(tid * 16 + i) * 2 + 0];
         s2 += red2[(tid * 16 + i) * 2 + 1];
       }
-      stat_add(stats + ((size_t)n * 16 + tid) * kStatW, s1, s2);
+      stat_add(stats + ((size_t)n * CO + tid) * kStatW, s1, s2);
     }
   }
 }
 
-// w_host: torch layout (16, 3, 3, 3) = [cout][cin][ky][kx]; w_dev receives [tap][cin][16]
-void pack_stem_weights(const float* w_host, float* packed /* 27 * 16 floats */) {
-  for (int co = 0; co < 16; ++co)
+// w_host: torch layout (cout, 3, 3, 3) = [cout][cin][ky][kx]; w_dev receives [tap][cin][cout]
+void pack_stem_weights(const float* w_host, float* packed /* 27 * cout floats */, int cout) {
+  for (int co = 0; co < cout; ++co)
     for (int ci = 0; ci < 3; ++ci)
-      for (int t = 0; t < 9; ++t) packed[(t * 3 + ci) * 16 + co] = w_host[(co * 3 + ci) * 9 + t];
+      for (int t = 0; t < 9; ++t) packed[(t * 3 + ci) * cout + co] = w_host[(co * 3 + ci) * 9 + t];
 }
 
 int launch_stem_conv(const Act& x, const float* w_dev, const Act& y, double* stats, hipStream_t s) {
-  JH_REQUIRE(x.Cp == 4 && y.Cp == 16 && x.D == 1 && y.H * 2 == x.H && y.W * 2 == x.W && x.N == y.N,
+  JH_REQUIRE(x.Cp == 4 && (y.Cp == 16 || y.Cp == 32) && x.D == 1 && y.H * 2 == x.H && y.W * 2 == x.W && x.N == y.N,
              "stem convolution shapes");
   JH_REQUIRE((size_t)x.H * x.W * 16 < ((size_t)1 << 31), "stem input too large");
   const int tiles = ((y.H + kStT - 1) / kStT) * ((y.W + kStT - 1) / kStT);
-  hipLaunchKernelGGL((stem_conv_kernel<0, 0>), dim3(tiles, x.N), dim3(256), 0, s, x.p, w_dev, y.p, stats, x.H, x.W,
-                     StemSrcArgs{});
+  if (y.Cp == 32)
+    hipLaunchKernelGGL((stem_conv_kernel<0, 0, 32>), dim3(tiles, x.N), dim3(256), 0, s, x.p, w_dev, y.p, stats, x.H,
+                       x.W, StemSrcArgs{});
+  else
+    hipLaunchKernelGGL((stem_conv_kernel<0, 0, 16>), dim3(tiles, x.N), dim3(256), 0, s, x.p, w_dev, y.p, stats, x.H,
+                       x.W, StemSrcArgs{});
   JH_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -173,8 +180,8 @@ int launch_stem_conv(const Act& x, const float* w_dev, const Act& y, double* sta
 int launch_stem_conv_src(const StemSource& src, const Act& x, const float* w_dev, const Act& y, double* stats,
                          hipStream_t s) {
   JH_REQUIRE(src.mode == 1 || src.mode == 2, "stem source mode");
-  JH_REQUIRE(x.Cp == 4 && y.Cp == 16 && x.D == 1 && y.H * 2 == x.H && y.W * 2 == x.W && x.N == y.N && x.H == x.W,
-             "stem convolution shapes");
+  JH_REQUIRE(x.Cp == 4 && (y.Cp == 16 || y.Cp == 32) && x.D == 1 && y.H * 2 == x.H && y.W * 2 == x.W && x.N == y.N &&
+                 x.H == x.W, "stem convolution shapes");
   StemSrcArgs sa{};
   sa.frames = src.frames; sa.frames_cell = src.frames_cell; sa.center_hm = src.center_hm;
   sa.Cloc = src.Cloc; sa.C = src.C; sa.cam0 = src.cam0; sa.FH = src.H; sa.FW = src.W;
@@ -187,7 +194,14 @@ int launch_stem_conv_src(const StemSource& src, const Act& x, const float* w_dev
   //  and loses locality with more workgroups in flight: 654 -> 711 us at eight per CU; 16 KB of unused dynamic LDS
   //  keep it at four.  The other forms are latency-bound and want the eight.)
   const size_t pad_f32 = JH_ENV_KNOB("JH_STEM_PAD_KB") >= 0 ? (size_t)JH_ENV_KNOB("JH_STEM_PAD_KB") * 1024 : 16384;
-#define JH_STEM(M, U) hipLaunchKernelGGL((stem_conv_kernel<M, U>), grid, dim3(256), (M == 1 && U == 0) ? pad_f32 : 0, s, x.p, w_dev, y.p, stats, x.H, x.W, sa)
+#define JH_STEM(M, U)                                                                                                   \
+  do {                                                                                                                  \
+    if (y.Cp == 32)                                                                                                     \
+      hipLaunchKernelGGL((stem_conv_kernel<M, U, 32>), grid, dim3(256), 0, s, x.p, w_dev, y.p, stats, x.H, x.W, sa);    \
+    else                                                                                                                \
+      hipLaunchKernelGGL((stem_conv_kernel<M, U, 16>), grid, dim3(256), (M == 1 && U == 0) ? pad_f32 : 0, s, x.p,       \
+                         w_dev, y.p, stats, x.H, x.W, sa);                                                              \
+  } while (0)
   if (src.mode == 1) { if (src.src_u8) JH_STEM(1, 1); else JH_STEM(1, 0); }
   else { if (src.src_u8) JH_STEM(2, 1); else JH_STEM(2, 0); }
 #undef JH_STEM

@@ -207,6 +207,7 @@ NODE_CASES = [  # (C, Cout, H, W, modes, act, n): the node shapes of the small /
     (88, 88, 32, 32, (0, 1), 2, 256),       # P4 top-down
     (88, 88, 32, 32, (0, 0, 0), 2, 256),    # P4 bottom-up with three same-level inputs
     (88, 88, 48, 32, (0, 1), 2, 192),       # ragged height
+    (88, 88, 16, 16, (0, 1), 2, 2048),      # P5 top-down of the medium model: one 16-pixel strip per image
 ]
 
 
