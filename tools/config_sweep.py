@@ -37,15 +37,16 @@ for case in range(n_cases):
     W, H = max(W, bbox + 8), max(H, bbox + 8)
     focal = rng.choice([500.0, 900.0, 1400.0])
     T = rng.choice([1, 1, 2, 8])
-    desc = dict(C=C, J=J, bbox=bbox, center=center, spacing=spacing, G=G, W=W, H=H, focal=focal, T=T)
+    size = rng.choice(["small", "small", "small", "medium"])      # (medium: the 88-channel pyramid, 32-channel stem)
+    desc = dict(C=C, J=J, bbox=bbox, center=center, spacing=spacing, G=G, W=W, H=H, focal=focal, T=T, size=size)
     try:
         calib = S.ring_calibration(C, W, H, focal)
-        sd_c = S.efficienttrack_weights("small", 1, 100 + case)
-        sd_h = S.hybridnet_weights("small", J, 200 + case)
+        sd_c = S.efficienttrack_weights(size, 1, 100 + case)
+        sd_h = S.hybridnet_weights(size, J, 200 + case)
         cfg = NS(PARENT_DIR="/nonexistent", PROJECT_NAME="sweep",
                  DATASET=NS(DATASET_ROOT_DIR="x", MEAN=S.MEAN, STD=S.STD),
-                 CENTERDETECT=NS(MODEL_SIZE="small", NUM_JOINTS=1, IMAGE_SIZE=center),
-                 KEYPOINTDETECT=NS(MODEL_SIZE="small", NUM_JOINTS=J, BOUNDING_BOX_SIZE=bbox),
+                 CENTERDETECT=NS(MODEL_SIZE=size, NUM_JOINTS=1, IMAGE_SIZE=center),
+                 KEYPOINTDETECT=NS(MODEL_SIZE=size, NUM_JOINTS=J, BOUNDING_BOX_SIZE=bbox),
                  HYBRIDNET=NS(NUM_CAMERAS=C, ROI_CUBE_SIZE=roi, GRID_SPACING=spacing))
         pred = JarvisPredictor3D(cfg, sd_c, sd_h)
         dev = [t.cuda() for t in calib]
@@ -65,7 +66,7 @@ for case in range(n_cases):
             with torch.no_grad():
                 rp, rc = O.predictor3d_forward(sd_c, sd_h, frames[t], *calib, center_size=center, bbox=bbox,
                                                roi_cube_size=roi, grid_spacing=spacing, mean=S.MEAN, std=S.STD,
-                                               chunk=5, intermediates=inter)
+                                               chunk=5, center_model=size, kp_model=size, intermediates=inter)
             pts, conf = got[t]
             assert (pts is None) == (rp is None), "validity differs on frame %d" % t
             if rp is None:
