@@ -655,6 +655,18 @@ def test_predict3d_frames_writes_csv(tmp_path, golden):
     for a, b in zip(r1[2:], r3[2:]):
         va, vb = [float(x) for x in a], [float(x) for x in b]
         assert max(abs(x - y) for x, y in zip(va, vb)) < 1e-3
+    # decode-in-place callables (the reference's read_images(cap, slice, imgs_orig) pattern): the pool
+    # threads write straight into the pinned staging buffer; same rows as the arrays above, on the cached buffers
+    import numpy as np
+    from jarvis_hybridnet_amd.prediction._ingest import release_ingest_buffers
+    fills = [(lambda dst, a=a: np.copyto(dst, a)) for a in sets]
+    nf = predict3D_frames(pred, fills, *dev, cfg, str(tmp_path / "fill"), time_batch=2, streams=3,
+                          frame_spec=(sets[0].shape, torch.uint8))
+    rf = list(csv.reader(open(tmp_path / "fill" / "data3D.csv")))
+    assert nf == 9 and rf == r3
+    assert len(pred._ingest_cache) >= 1
+    release_ingest_buffers(pred)
+    assert not hasattr(pred, "_ingest_cache")
 
 
 def test_forward_is_bitwise_reproducible():
