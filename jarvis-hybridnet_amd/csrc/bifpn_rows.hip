@@ -358,12 +358,17 @@ void bifpn_rows_kernel(const NodeArgs a, int seg_rows, int strips) {
 // Which nodes take the row-streaming form: the 56-channel (small model) or 88-channel (medium) pyramid with as many
 // output column blocks as the input has, no max-pooled input, level at least 32 pixels wide and a multiple of 16
 // (JH_NODE_ROWS=0: never; JH_NODE_ROWS88=0: not at 88 channels).
+bool bifpn_rows_wg_shape_ok(const NodeArgs& a);                 // csrc/bifpn_rows_wg.hip
+int launch_bifpn_rows_wg(const NodeArgs& a, hipStream_t s);
+
 bool bifpn_rows_eligible(const NodeArgs& a) {
   if (JH_ENV_KNOB("JH_NODE_ROWS") == 0 || a.rows == 0) return false;
-  if (a.Cp != 56 && !(a.Cp == 88 && JH_ENV_KNOB("JH_NODE_ROWS88") != 0)) return false;
-  // (88 channels: also the 16-pixel-wide level -- one strip per image -- because the tile kernel's path for more than
-  //  64 channels is slow there, 0.10 ms per launch against 0.05; at 56 channels the tile kernel wins below 32 pixels)
-  if (a.cout_p16 != (a.Cp + 15) / 16 * 16 || a.W % 16 != 0 || a.W < (a.Cp == 88 ? 16 : 32) || a.H < 16) return false;
+  // (160 channels, the large model: the workgroup form, csrc/bifpn_rows_wg.hip; JH_NODE_ROWS160=0: tile form)
+  const bool wg = a.Cp == 160 && JH_ENV_KNOB("JH_NODE_ROWS160") != 0 && bifpn_rows_wg_shape_ok(a);
+  if (a.Cp != 56 && !(a.Cp == 88 && JH_ENV_KNOB("JH_NODE_ROWS88") != 0) && !wg) return false;
+  // (88 / 160 channels: also the 16-pixel-wide level -- one strip per image -- because the tile kernel's path for more
+  //  than 64 channels is slow there, 0.10 ms per launch against 0.05; at 56 channels the tile kernel wins below 32 pixels)
+  if (a.cout_p16 != (a.Cp + 15) / 16 * 16 || a.W % 16 != 0 || a.W < (a.Cp >= 88 ? 16 : 32) || a.H < 16) return false;
   if (a.mode[0] != FUSE_SAME) return false;
   if (a.rows < 0) {
     // (one wave per workgroup walking >= 10 rows: below ~2048 strips the chip is not filled and the tile form wins)
@@ -413,6 +418,7 @@ static int launch_rows_rc(const NodeArgs& a, hipStream_t s) {
 }
 
 int launch_bifpn_rows(const NodeArgs& a, hipStream_t s) {
+  if (a.Cp == 160) return launch_bifpn_rows_wg(a, s);
   if (a.Cp == 88) return launch_rows_rc<88>(a, s);
   return launch_rows_rc<56>(a, s);
 }

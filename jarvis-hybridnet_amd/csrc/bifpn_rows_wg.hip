@@ -1,0 +1,316 @@
+// Fused BiFPN node, row-streaming form for the WIDE pyramids (160 channels: the large model; round 4).
+//
+// Same function and the same walk as bifpn_rows.hip (fusion of 2-3 inputs with InstanceNorm on load, activation,
+// depthwise 3x3, pointwise 1x1 + bias, statistics of the output; jarvis/efficienttrack/model.py:309-353 +
+// :223-232), but a strip 16 pixels wide belongs to a WORKGROUP of RC / 16 waves instead of one wave: at 160
+// channels the pointwise weights (160 x 160 fp32 = 102 KB) fit neither one wave's registers (400 per lane) nor,
+// next to anything else, the LDS -- the tile kernel re-streams them per tile and runs at 8-15 % of HBM there
+// (3.6 ms per P3 node of the large model at 384 images).  Here
+//   * wave w owns the 16 channels [16 w, 16 w + 16) on BOTH sides of the depthwise: it fuses them into its own
+//     channel slice of the three-row ring in LDS (no synchronisation: the depthwise reads per channel), and it owns
+//     output column block w of the pointwise: its 16 x RC weight slice stays in RC / 4 = 40 registers for the strip,
+//   * the 16 x RC operand block (depthwise output of one row) is the only thing the waves share: double-buffered by
+//     row parity, ONE workgroup barrier per row (LDS traffic only: the next row's global loads stay in flight),
+//   * per row and wave: 2 fused items per lane (18 pixels x 4 quads over 64 lanes), one depthwise pixel per lane
+//     (9 ring reads, 9 packed FMAs), RC / 8 operand reads + RC / 4 MFMAs (two accumulators: even / odd channel
+//     pairs), bias + statistics + one 16-byte store; the 2 x 2 max-pooled output is carried in registers between the
+//     two halves of the unrolled row loop, so every variant can write it.
+// One workgroup (10 waves at 160 channels, <= 168 registers) per CU; 55.5 KB of LDS.
+#include <algorithm>
+#include <type_traits>
+
+#include "conv_mfma.h"
+#include "bifpn_node.h"
+
+namespace jh {
+
+namespace {
+constexpr int kWPX18 = 18;                         // ring row width: 16 pixels + the depthwise halo
+template <int RC>
+struct RowWgGeo {
+  static constexpr int NW = RC / 16;               // waves per workgroup = channel groups = output column blocks
+  static constexpr int K8 = RC / 8;
+  static constexpr int RSA = RC + 4;               // operand-block row stride (floats): 16 rows on distinct banks
+  static constexpr int ROWB = kWPX18 * RC * 4;     // bytes per ring row
+  static constexpr int OPB = 16 * RSA * 4;         // bytes per operand block
+  static constexpr size_t lds_bytes() { return (size_t)3 * ROWB + 2 * OPB; }
+  static_assert(RC % 16 == 0 && NW <= 16, "channel count of the workgroup row-streaming node");
+};
+typedef float wf2 __attribute__((ext_vector_type(2)));
+typedef float wf4 __attribute__((ext_vector_type(4)));
+typedef unsigned wu4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+}  // namespace
+
+template <int RC, int NIN, int M1, int M2, int ACT, bool POOL>
+__global__ __launch_bounds__(RowWgGeo<RC>::NW * 64)
+void bifpn_rows_wg_kernel(const NodeArgs a, int seg_rows, int strips) {
+  using GEO = RowWgGeo<RC>;
+  constexpr int K8 = GEO::K8, RSA = GEO::RSA, kRowB = GEO::ROWB, kOpOff = 3 * GEO::ROWB, kOpB = GEO::OPB;
+  constexpr int kModes[3] = {FUSE_SAME, M1, M2};
+  constexpr int NIT = 2;                           // fused items per lane: pixels sub and 16 + sub (sub < 2)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane & 3, sub = lane >> 2;         // channel quad inside the wave's 16 channels, pixel slot 0..15
+  const int c = wave * 16 + q * 4;
+  const int sx = blockIdx.x % strips, seg = blockIdx.x / strips, n = blockIdx.y;
+  const int ox0 = sx * 16, y_begin = seg * seg_rows, y_end = min(a.H, y_begin + seg_rows);
+  const int mrow = lane & 15, kq = lane >> 4;
+
+  // ---- per-lane constants --------------------------------------------------------------------------------
+  // folded norm + fusion weights of this lane's channel quad: fused = sum_k x_k a_k + B
+  wf4 ak[NIN], bb = (wf4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < NIN; ++k) {
+    float m4[4] = {0.f, 0.f, 0.f, 0.f}, r4[4] = {1.f, 1.f, 1.f, 1.f};
+    if (a.st[k]) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const double* st = a.st[k] + ((size_t)n * RC + c + j) * kStatW;
+        const double mu = exact_read(st) * (double)a.inv_cnt[k];
+        double var = exact_read(st + kLimbs) * (double)a.inv_cnt[k] - mu * mu;
+        if (var < 0.0) var = 0.0;
+        m4[j] = (float)mu;
+        r4[j] = (float)(1.0 / sqrt(var + 1e-5));
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float ak1 = a.w[k] * r4[j];
+      ak[k][j] = ak1;
+      bb[j] += -m4[j] * ak1;
+    }
+  }
+  wf4 dwr[9];                                      // depthwise weights of this lane's channel quad
+#pragma unroll
+  for (int t = 0; t < 9; ++t) dwr[t] = *reinterpret_cast<const wf4*>(a.dw + t * RC + c);
+  // pointwise weights of output column block `wave` for all RC / 8 channel steps (packed as for bifpn_rows.hip:
+  // weights are the A operand, pixels the B operand, so a lane's accumulator is four consecutive channels
+  // 16 wave + 4 (lane >> 4) .. + 3 of pixel lane & 15)
+  constexpr int NCB = RC / 16;
+  wf2 bw[K8];
+#pragma unroll
+  for (int k8 = 0; k8 < K8; ++k8)
+    bw[k8] = *reinterpret_cast<const wf2*>(a.pw + ((size_t)(k8 * NCB + wave) * 64 + lane) * 2);
+  wf4 b4 = (wf4){0.f, 0.f, 0.f, 0.f};
+  if (a.bias) b4 = *reinterpret_cast<const wf4*>(a.bias + wave * 16 + kq * 4);
+
+  __amdgpu_buffer_rsrc_t rs[NIN];
+  int rowstep[NIN];                                // bytes per source row of input k
+#pragma unroll
+  for (int k = 0; k < NIN; ++k) {
+    const int sh = kModes[k] == FUSE_UP2 ? 1 : (kModes[k] == FUSE_UP4 ? 2 : 0);
+    const size_t plane = node_plane(kModes[k], a.H, a.W) * RC;
+    rs[k] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in[k] + (size_t)n * plane), 0, (int)(plane * 4),
+                                              0x00020000);
+    rowstep[k] = (a.W >> sh) * RC * 4;
+  }
+  // the two items of this lane in a fused row (pixels sub and 16 + sub of the 18): load offsets inside a source row
+  // (bit 31 = outside the image or no item: the buffer load returns 0) and the 0 / 1 mask of the zero padding
+  int voff[NIN][NIT];
+  float msk[NIT];
+  bool has[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int px = it * 16 + sub, ix = ox0 - 1 + px;
+    has[it] = px < kWPX18;
+    const bool ok = has[it] && (unsigned)ix < (unsigned)a.W;
+    msk[it] = ok ? 1.f : 0.f;
+#pragma unroll
+    for (int k = 0; k < NIN; ++k) {
+      const int sh = kModes[k] == FUSE_UP2 ? 1 : (kModes[k] == FUSE_UP4 ? 2 : 0);
+      voff[k][it] = ok ? ((ix >> sh) * RC + c) * 4 : (int)0x80000000;
+    }
+  }
+  const int fdst = (sub * RC + c) * 4;                          // + 16 pixels (imm) + ring slot
+  const int dsrc = (sub * RC + c) * 4;                          // + ring slot + tap pixel (imm)
+  const int adst = kOpOff + (sub * RSA + c) * 4;                // + operand buffer
+  const int ard = kOpOff + (mrow * RSA) * 4 + kq * 8;           // + operand buffer + channel step (imm)
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+      a.y + (size_t)n * a.H * a.W * a.cout_p, 0, (int)((size_t)a.H * a.W * a.cout_p * 4), 0x00020000);
+  const int yoff = ((ox0 + mrow) * a.cout_p + wave * 16 + kq * 4) * 4;
+  // POOL: the node also writes MaxPool2d(2, 2) of its raw output (max commutes with the monotone InstanceNorm map,
+  // the pooled tensor keeps this node's statistics).  Horizontal max: the neighbour pixel is lane ^ 1 (one DPP
+  // move); vertical: the even row's maxima wait in registers for the odd row.  Lanes of even pixels own the pixel.
+  __amdgpu_buffer_rsrc_t rp = ry;
+  int pbase = (int)0x80000000;
+  if (POOL) {
+    rp = __builtin_amdgcn_make_buffer_rsrc(a.y_pool + (size_t)n * (a.H >> 1) * (a.W >> 1) * a.cout_p, 0,
+                                           (int)((size_t)(a.H >> 1) * (a.W >> 1) * a.cout_p * 4), 0x00020000);
+    if (!(mrow & 1)) pbase = (((ox0 + mrow) >> 1) * a.cout_p + wave * 16 + kq * 4) * 4;
+  }
+  wf4 park = (wf4){0.f, 0.f, 0.f, 0.f};
+  wf4 raw[NIN][NIT];
+  // (see bifpn_rows.hip: an up-sampled input changes its source row only every 2nd output row; `all_c` is a
+  //  compile-time flag because loads under a run-time branch make the compiler's in-order wait counts pessimistic)
+  auto issue = [&](int yf, auto all_c) __attribute__((always_inline)) {       // (yf inside the image)
+    constexpr bool all = decltype(all_c)::value;
+    int srow[NIN];
+#pragma unroll
+    for (int k = 0; k < NIN; ++k) {
+      const int sh = kModes[k] == FUSE_UP2 ? 1 : (kModes[k] == FUSE_UP4 ? 2 : 0);
+      srow[k] = (yf >> sh) * rowstep[k];
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+#pragma unroll
+      for (int k = 0; k < NIN; ++k)
+        if (all || kModes[k] == FUSE_SAME)
+          raw[k][it] =
+              __builtin_bit_cast(wf4, __builtin_amdgcn_raw_buffer_load_b128(rs[k], voff[k][it], srow[k], 0));
+  };
+  // fused + activated row yf -> ring slot (yf + 1) % 3 (zeros outside the image: the depthwise padding)
+  auto fuse = [&](int yf, int slot) __attribute__((always_inline)) {
+    unsigned char* dst = smem + slot * kRowB + fdst;
+    if ((unsigned)yf >= (unsigned)a.H) {                             // (uniform) padding row
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+        if (has[it]) *reinterpret_cast<wf4*>(dst + it * 16 * RC * 4) = (wf4){0.f, 0.f, 0.f, 0.f};
+      return;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      wf4 v = bb;
+#pragma unroll
+      for (int k = 0; k < NIN; ++k) v = __builtin_elementwise_fma(raw[k][it], ak[k], v);
+      if (ACT == ACT_SILU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] * __builtin_amdgcn_rcpf(1.f + __expf(-v[j]));
+      } else if (ACT == ACT_RELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+      // (pixel 0 of the strip is item 0 of the lanes sub == 0, pixel 17 item 1 of sub == 1: both items are masked)
+      v *= (wf4){msk[it], msk[it], msk[it], msk[it]};
+      if (has[it]) *reinterpret_cast<wf4*>(dst + it * 16 * RC * 4) = v;
+    }
+  };
+
+  wf4 s1 = (wf4){0.f, 0.f, 0.f, 0.f}, s2 = s1;
+  __builtin_amdgcn_s_waitcnt(0);                   // (the preamble's loads: see bifpn_rows.hip)
+  int slot = (y_begin + 3) % 3;                    // slot of row yf = y_begin - 1: (yf + 1) % 3
+
+  auto row = [&](int yf, auto next_all_c, auto out_c) __attribute__((always_inline)) {
+    fuse(yf, slot);
+    if (yf + 1 <= y_end && yf + 1 < a.H) issue(yf + 1, next_all_c);
+    const int y = yf - 1;                               // output row whose three ring rows are now complete
+    const int s_top = slot == 0 ? 1 : (slot == 1 ? 2 : 0);          // slot of row y - 1 = (slot + 1) % 3
+    slot = s_top;
+    if (!decltype(out_c)::value) return;             // (the two rows above the segment's first output row)
+    // the operand buffer of this row: by row parity (next_all_c is true in the half of the unrolled loop that
+    // produces the EVEN output rows)
+    constexpr int kBuf = decltype(next_all_c)::value ? 0 : kOpB;
+    // ---- depthwise 3x3: lane = (pixel, channel quad of the wave's 16 channels) -> operand block ------------
+    {
+      int rs_ = s_top;
+      wf4 d = (wf4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const unsigned char* src = smem + rs_ * kRowB + dsrc;
+        rs_ = rs_ == 2 ? 0 : rs_ + 1;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+          d = __builtin_elementwise_fma(*reinterpret_cast<const wf4*>(src + dx * RC * 4), dwr[dy * 3 + dx], d);
+      }
+      *reinterpret_cast<wf4*>(smem + adst + kBuf) = d;
+    }
+    lds_barrier();                                   // every channel group of the operand block is written
+    // ---- pointwise 1x1: 16 output channels x 16 pixels x RC channels on the matrix cores --------------------
+    f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+    for (int k8 = 0; k8 < K8; ++k8) {
+      const float2 xc = *reinterpret_cast<const float2*>(smem + ard + kBuf + k8 * 32);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[k8][0], xc.x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[k8][1], xc.y, acc1, 0, 0, 0);
+    }
+    // ---- bias, statistics (in registers across the strip), one 16-byte store ---------------------------------
+    const wf4 v = ((wf4){acc0[0], acc0[1], acc0[2], acc0[3]} + (wf4){acc1[0], acc1[1], acc1[2], acc1[3]}) + b4;
+    s1 += v;
+    s2 = __builtin_elementwise_fma(v, v, s2);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wu4, v), ry, yoff + y * a.W * a.cout_p * 4, 0, 0);
+    if (POOL) {
+      wf4 hm;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        hm[j] = fmaxf(v[j], __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v[j]), 0xB1, 0xF, 0xF, true)));
+      if (decltype(next_all_c)::value) {                                  // even output row: keep
+        park = hm;
+      } else {                                                            // odd row: combine, store
+        wf4 pv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pv[j] = fmaxf(park[j], hm[j]);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wu4, pv), rp,
+                                               pbase + (y >> 1) * (a.W >> 1) * a.cout_p * 4, 0, 0);
+      }
+    }
+  };
+  // (segments start on even rows -- the launcher -- so row y_begin - 1 is odd and the rows requested from the first
+  //  half of the unrolled body are even: all inputs; from the second half odd: same-level inputs only)
+  if (y_begin - 1 >= 0) issue(y_begin - 1, std::true_type{});
+  row(y_begin - 1, std::true_type{}, std::false_type{});
+  row(y_begin, std::false_type{}, std::false_type{});
+  for (int yf = y_begin + 1; yf <= y_end; yf += 2) {
+    row(yf, std::true_type{}, std::true_type{});
+    if (yf + 1 <= y_end) row(yf + 1, std::false_type{}, std::true_type{});
+  }
+  if (a.stats) {
+    // sum over the 16 pixel lanes of a DPP row: xor 1, xor 2 (quad permutes), half-row mirror, row mirror
+    auto row_sum = [](float x) __attribute__((always_inline)) {
+      x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true));
+      x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xF, 0xF, true));
+      x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x141, 0xF, 0xF, true));
+      x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x140, 0xF, 0xF, true));
+      return x;
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float t1 = row_sum(s1[i]), t2 = row_sum(s2[i]);
+      const int ch = wave * 16 + kq * 4 + i;
+      if (mrow == 0) stat_add(a.stats + ((size_t)n * a.cout_p + ch) * kStatW, t1, t2);
+    }
+  }
+}
+
+// Shapes of the workgroup form (the channel count is checked by the caller, bifpn_rows_eligible): as many output
+// channels as input channels, no padding in either.
+bool bifpn_rows_wg_shape_ok(const NodeArgs& a) {
+  return a.Cp == 160 && a.cout_p == a.Cp && a.cout_p16 == a.Cp;
+}
+
+int launch_bifpn_rows_wg(const NodeArgs& a, hipStream_t s) {
+  constexpr int RC = 160;
+  const int strips = a.W / 16;
+  // Rows per workgroup: a function of the node ONLY (the float partial sums of the statistics are taken per strip
+  // segment: bit-equal results for any number of images per launch), as in bifpn_rows.hip.
+  int seg_rows = JH_ENV_KNOB("JH_NODE_SEG") > 0 ? JH_ENV_KNOB("JH_NODE_SEG")
+                 : (a.n_in == 2 || a.mode[1] == FUSE_SAME ? std::max(8, a.H / 2) : (a.H >= 64 ? 16 : 8));
+  seg_rows = (seg_rows + 1) & ~1;
+  if (seg_rows > a.H) seg_rows = a.H;
+  const int segs = (a.H + seg_rows - 1) / seg_rows;
+  const size_t lds = RowWgGeo<RC>::lds_bytes();
+  const dim3 grid(strips * segs, a.N), block(RowWgGeo<RC>::NW * 64);
+#define JH_ROWS(NIN, M1, M2, ACT, POOL) \
+  hipLaunchKernelGGL((bifpn_rows_wg_kernel<RC, NIN, M1, M2, ACT, POOL>), grid, block, lds, s, a, seg_rows, strips)
+  JH_REQUIRE(!a.y_pool || (a.act == ACT_SILU && a.H % 2 == 0 && (a.n_in == 2 || a.mode[1] == FUSE_SAME)),
+             "workgroup row-streaming node: pooled output");
+  if (a.n_in == 2) {
+    if (a.act == ACT_SILU && a.y_pool) JH_ROWS(2, FUSE_UP2, 0, ACT_SILU, true);
+    else if (a.act == ACT_SILU) JH_ROWS(2, FUSE_UP2, 0, ACT_SILU, false);
+    else if (a.act == ACT_NONE) JH_ROWS(2, FUSE_UP2, 0, ACT_NONE, false);
+    else JH_REQUIRE(false, "row-streaming node: activation");
+  } else if (a.mode[1] == FUSE_SAME) {
+    if (a.act == ACT_SILU && a.y_pool) JH_ROWS(3, FUSE_SAME, FUSE_SAME, ACT_SILU, true);
+    else if (a.act == ACT_SILU) JH_ROWS(3, FUSE_SAME, FUSE_SAME, ACT_SILU, false);
+    else JH_REQUIRE(false, "row-streaming node: activation");
+  } else {
+    if (a.act == ACT_SILU) JH_ROWS(3, FUSE_UP2, FUSE_UP4, ACT_SILU, false);
+    else if (a.act == ACT_NONE) JH_ROWS(3, FUSE_UP2, FUSE_UP4, ACT_NONE, false);
+    else JH_REQUIRE(false, "row-streaming node: activation");
+  }
+#undef JH_ROWS
+  JH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace jh

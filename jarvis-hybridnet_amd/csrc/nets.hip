@@ -397,7 +397,10 @@ int EffTrackPlan::node(const ParamMap& pm, const std::string& cp, int n_in, cons
     // the row-streaming two-input form can write the 2x2-max-pooled raw output on the side (bifpn_rows.hip): the
     // bottom-up node of the next level then reads a same-resolution tensor with THIS node's statistics
     pooled->a = Act{};
-    if (n_in == 2 && act == ACT_SILU && out->a.Cp == like.Cp && like.H % 2 == 0 && bifpn_rows_eligible(a)) {
+    // (160 channels, csrc/bifpn_rows_wg.hip: also the node with three same-level inputs, so the bottom-up pass stays in
+    //  the row-streaming form one level further down)
+    const bool same3 = n_in == 3 && modes[1] == FUSE_SAME && modes[2] == FUSE_SAME && like.Cp == 160;
+    if ((n_in == 2 || same3) && act == ACT_SILU && out->a.Cp == like.Cp && like.H % 2 == 0 && bifpn_rows_eligible(a)) {
       if (new_act(like.N, 1, like.H / 2, like.W / 2, cout, &pooled->a)) return 1;
       pooled->st = (long)st; pooled->inv = out->inv; pooled->act = out->act;
       a.y_pool = pooled->a.p;
@@ -522,15 +525,22 @@ int EffTrackPlan::build(const ParamMap& pm, const std::string& pre, int size, in
     { const Ref in[2] = {p4_in, p5_up}; if (fnode("p4_w1", 2, in, m_up, p4_in, "conv4_up", &p4_up)) return 1; }
     Ref p3_pool;
     { const Ref in[2] = {p3_in, p4_up}; if (fnode("p3_w1", 2, in, m_up, p3_in, "conv3_up", &p3_out, &p3_pool)) return 1; }
+    const int m_same3[3] = {FUSE_SAME, FUSE_SAME, FUSE_SAME};
+    Ref p4_pool;
     if (p3_pool.a.p) {          // (time batches: P3's node wrote its pooled output, all three inputs at P4's resolution)
-      const int m_same3[3] = {FUSE_SAME, FUSE_SAME, FUSE_SAME};
       const Ref in[3] = {p4_in2, p4_up, p3_pool};
-      if (fnode("p4_w2", 3, in, m_same3, p4_in2, "conv4_down", &p4_out)) return 1;
+      if (fnode("p4_w2", 3, in, m_same3, p4_in2, "conv4_down", &p4_out, &p4_pool)) return 1;
     } else {
       const Ref in[3] = {p4_in2, p4_up, p3_out};
       if (fnode("p4_w2", 3, in, m_dn3, p4_in2, "conv4_down", &p4_out)) return 1;
     }
-    { const Ref in[3] = {p5_in2, p5_up, p4_out}; if (fnode("p5_w2", 3, in, m_dn3, p5_in2, "conv5_down", &p5_out)) return 1; }
+    if (p4_pool.a.p) {          // (160 channels: P4's bottom-up node wrote its pooled output too)
+      const Ref in[3] = {p5_in2, p5_up, p4_pool};
+      if (fnode("p5_w2", 3, in, m_same3, p5_in2, "conv5_down", &p5_out)) return 1;
+    } else {
+      const Ref in[3] = {p5_in2, p5_up, p4_out};
+      if (fnode("p5_w2", 3, in, m_dn3, p5_in2, "conv5_down", &p5_out)) return 1;
+    }
     // the head reads p3, p4, p5 of the last cell only: its p6 / p7 outputs are dead
     if (cell + 1 < ss.cells) {
       { const Ref in[3] = {p6_in, p6_up, p5_out}; if (fnode("p6_w2", 3, in, m_dn3, p6_in, "conv6_down", &p6_out)) return 1; }

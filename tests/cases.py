@@ -92,6 +92,10 @@ PREDICTOR_CASES = {
     "cfg3_medium": dict(C=12, J=23, roi=128, spacing=2, bbox=256, center_size=256,
                         W=1280, H=1024, focal=1800.0, cseed=66, hseed=63, fseed=52,
                         size="medium"),
+    # ... and with the 'large' models (160-channel pyramid: the workgroup row-streaming BiFPN nodes at time batch >= 8)
+    "cfg3_large": dict(C=12, J=23, roi=128, spacing=2, bbox=256, center_size=256,
+                       W=1280, H=1024, focal=1800.0, cseed=71, hseed=72, fseed=53,
+                       size="large"),
 }
 
 

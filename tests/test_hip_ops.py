@@ -208,6 +208,15 @@ NODE_CASES = [  # (C, Cout, H, W, modes, act, n): the node shapes of the small /
     (88, 88, 32, 32, (0, 0, 0), 2, 256),    # P4 bottom-up with three same-level inputs
     (88, 88, 48, 32, (0, 1), 2, 192),       # ragged height
     (88, 88, 16, 16, (0, 1), 2, 2048),      # P5 top-down of the medium model: one 16-pixel strip per image
+    # the large model's 160-channel pyramid: workgroup row-streaming form (csrc/bifpn_rows_wg.hip: ten waves per
+    # strip, one output column block and one 16-channel slice of the ring each)
+    (160, 160, 32, 32, (0, 0, 3), 2, 3),    # tile form (small launch)
+    (160, 160, 64, 64, (0, 1), 2, 64),      # P3 top-down
+    (160, 160, 64, 64, (0, 1, 2), 0, 64),   # three inputs x1 / x2 / x4, no activation
+    (160, 160, 32, 32, (0, 1), 2, 256),     # P4 top-down
+    (160, 160, 32, 32, (0, 0, 0), 2, 256),  # P4 bottom-up with three same-level inputs
+    (160, 160, 48, 32, (0, 1), 2, 192),     # ragged height
+    (160, 160, 16, 16, (0, 1), 2, 2048),    # P5 top-down: one strip per image
 ]
 
 

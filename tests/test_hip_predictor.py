@@ -44,7 +44,7 @@ def test_hybridnet_backbone(tag, golden):
     check_summary(g, tag + ".heatmap_final", fin.cpu(), rtol=1e-3, atol=1e-3)
 
 
-@pytest.mark.parametrize("tag", ["cfg2", "cfg3", "cfg2_none", "cfg2_u8", "cfg5", "ex72", "cfg3_medium"])
+@pytest.mark.parametrize("tag", ["cfg2", "cfg3", "cfg2_none", "cfg2_u8", "cfg5", "ex72", "cfg3_medium", "cfg3_large"])
 def test_predictor3d(tag, golden):
     """JarvisPredictor3D.forward vs the imported reference's output on the same input
     (tests/golden/predictor.npz).  ex72 = the geometry the reference ships (Example_Project: 72^3 grid, V2V at
@@ -80,13 +80,14 @@ def test_predictor3d(tag, golden):
     assert ec < 1e-4
 
 
-@pytest.mark.parametrize("tag", ["ex72", "cfg3", "cfg3_medium"])
+@pytest.mark.parametrize("tag", ["ex72", "cfg3", "cfg3_medium", "cfg3_large"])
 def test_predictor3d_time_batch_8_vs_fixture(tag, golden):
     """The time_batch >= 8 class (row-streaming BiFPN nodes: the form bench.py times) held to the REFERENCE fixture
     directly: frame 0 of an 8-frame-set call is the fixture case; the other seven are distinct subjects and
     must agree with their single-frame calls.  ex72 = the reference's shipped geometry (72^3 grid: cube gather on
     a grid that is not a multiple of 16, V2V at 36^3 / 18^3 with partial Winograd tiles); cfg3_medium = the
-    reference's default model size, whose 88-channel pyramid runs the row-streaming nodes from time_batch 8 on."""
+    reference's default model size, whose 88-channel pyramid runs the row-streaming nodes from time_batch 8 on;
+    cfg3_large = the 160-channel pyramid (workgroup row-streaming nodes, csrc/bifpn_rows_wg.hip)."""
     from jarvis_hybridnet_amd import synthetic as S
     from jarvis_hybridnet_amd.prediction.jarvis3D import JarvisPredictor3D
     c = cases.PREDICTOR_CASES[tag]

@@ -119,7 +119,7 @@ def test_hybridnet(golden, tag):
     check_summary(g, tag + ".heatmaps_padded", hm, **TOL)
 
 
-@pytest.mark.parametrize("tag", ["cfg2", "cfg2_none", "cfg2_u8", "cfg5", "ex72", "cfg3_medium"])
+@pytest.mark.parametrize("tag", ["cfg2", "cfg2_none", "cfg2_u8", "cfg5", "ex72", "cfg3_medium", "cfg3_large"])
 def test_predictor(golden, tag):
     c = cases.PREDICTOR_CASES[tag]
     inp = cases.predictor_inputs(tag)
