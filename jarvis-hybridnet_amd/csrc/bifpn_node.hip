@@ -447,6 +447,51 @@ __global__ __launch_bounds__(512, 6) void bifpn_node_kernel(const NodeArgs a) {
         for (int nr = 0; nr < kNodeNRG; ++nr)
           acc[0][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac.y, bc[nr].y, acc[0][nr], 0, 0, 0);
       }
+    } else if (!a.alias && kNodePY * kNodePX * SF >= nk8 * kNodeNRG * 128 && nk8 * kNodeNRG * 32 <= 6 * NT &&
+               !(a.abl & 32)) {
+      // Wide pyramids (88 / 160 channels; round 4): the weights of this group of column blocks go through the dead
+      // halo tile in ONE cooperative copy (all its loads in flight at once) instead of one L2 round trip per
+      // channel step -- with 8 MFMAs per step and two waves per SIMD the two-deep register prefetch below covers
+      // about half of an L2 latency, and a tile of the 160-channel pyramid spent 60 such steps (the nodes of the
+      // 8 x 8 and smaller levels: 130-220 us per launch whatever their size).
+      const int gcb = min(kNodeNRG, nb - nb0);
+      const int per_k8 = gcb * 32, total = nk8 * per_k8;                 // float4 items
+      const float4* src = reinterpret_cast<const float4*>(a.pw);
+      float4 t[6];
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const int idx = tid + u * NT;
+        if (idx < total) {
+          const int k8 = idx / per_k8, j = idx - k8 * per_k8;
+          t[u] = src[(size_t)(k8 * nb + nb0) * 32 + j];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const int idx = tid + u * NT;
+        if (idx < total) {
+          const int k8 = idx / per_k8, j = idx - k8 * per_k8;
+          reinterpret_cast<float4*>(Ft)[k8 * (kNodeNRG * 32) + j] = t[u];
+        }
+      }
+      __syncthreads();
+      const float2* B2 = reinterpret_cast<const float2*>(Ft) + lane;
+      int lo[kNodeNRG];
+#pragma unroll
+      for (int nr = 0; nr < kNodeNRG; ++nr) lo[nr] = min(nr, gcb - 1) * 64;
+#pragma unroll 1
+      for (int k8 = 0; k8 < nk8; ++k8) {
+        const float2 ac = A2[abase + k8 * 4];
+        float2 bc[kNodeNRG];
+#pragma unroll
+        for (int nr = 0; nr < kNodeNRG; ++nr) bc[nr] = B2[k8 * (kNodeNRG * 64) + lo[nr]];
+#pragma unroll
+        for (int nr = 0; nr < kNodeNRG; ++nr)
+          acc[0][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac.x, bc[nr].x, acc[0][nr], 0, 0, 0);
+#pragma unroll
+        for (int nr = 0; nr < kNodeNRG; ++nr)
+          acc[0][nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac.y, bc[nr].y, acc[0][nr], 0, 0, 0);
+      }
     } else {
       float2 bn[kNodeNRG], bnn[kNodeNRG];
 #pragma unroll

@@ -12,6 +12,7 @@ python3 bench.py --config cfg5 --time-batch 8 --no-secondary > gpurun_out/${tag}
 python3 bench.py --config cfg2 --no-secondary > gpurun_out/${tag}_bench_cfg2_3x32.json 2> /dev/null
 python3 bench.py --config ex72 --no-secondary --no-cpu-baseline > gpurun_out/${tag}_bench_ex72_3x24.json 2> /dev/null
 python3 bench.py --model-size medium --no-secondary --no-cpu-baseline --no-uint8 --no-reduced-precision > gpurun_out/${tag}_bench_cfg3_medium_3x32.json 2> /dev/null
+python3 bench.py --model-size large --no-secondary --no-cpu-baseline --no-uint8 --no-reduced-precision > gpurun_out/${tag}_bench_cfg3_large_3x32.json 2> /dev/null
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/kt_final
 rocprofv3 --kernel-trace --stats -d /tmp/kt_final -o run -- python3 $root/bench.py --streams 1 --steps 10 --warmup 3 \
   --no-cpu-baseline --no-uint8 --no-secondary > /tmp/kt_final.log 2>&1
