@@ -17,3 +17,12 @@ def test_config_sweep(seed):
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "config_sweep.py"), "10", str(seed)], cwd=ROOT,
                          capture_output=True, text=True, timeout=1500)
     assert res.returncode == 0 and "0 of 10 cases failed" in res.stdout, res.stdout[-3000:] + res.stderr[-1500:]
+
+
+def test_frames_beyond_2gb_per_time_batch():
+    """4K cameras, time batch 8: 2.4 GB of fp32 frames in one call (byte offsets past 2^31 inside the frame buffer)
+    through the HIP path against the CPU oracle, plus the single-frame and uint8 entry points on the same frames
+    (tools/big_frame_check.py)."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "big_frame_check.py"), "3840", "2160", "3", "8"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert res.returncode == 0 and "big frame check: worst" in res.stdout, res.stdout[-3000:] + res.stderr[-1500:]
