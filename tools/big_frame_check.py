@@ -1,5 +1,6 @@
-"""One-off robustness check: frames much larger than the BASELINE configs (4K cameras, time batch 8: > 2^31 bytes per
-time batch) through the HIP path against the CPU oracle.  python tools/big_frame_check.py [W H C T]"""
+"""Robustness check at the edges of the configuration space: frames much larger than the BASELINE configs (4K cameras,
+time batch 8: > 2^31 bytes per time batch), many cameras, many joints, large grids -- through the HIP path against the
+CPU oracle.  python tools/big_frame_check.py [W H C T [J=.. bbox=.. center=.. spacing=.. G=.. focal=.. size=..]]"""
 import os
 import sys
 from types import SimpleNamespace as NS
@@ -14,6 +15,10 @@ from oracle import hybridnet_oracle as O
 
 W, H, C, T = (int(v) for v in (sys.argv[1:5] if len(sys.argv) > 4 else (3840, 2160, 4, 8)))
 J, bbox, center, spacing, G, focal, size = 4, 256, 256, 2, 32, 3200.0, "small"
+for kv in sys.argv[5:]:                      # further key=value overrides: J= bbox= center= spacing= G= focal= size=
+    k, val = kv.split("=")
+    assert k in ("J", "bbox", "center", "spacing", "G", "focal", "size"), k
+    globals()[k] = val if k == "size" else (float(val) if k == "focal" else int(val))
 roi = G * spacing
 torch.set_num_threads(16)
 calib = S.ring_calibration(C, W, H, focal)
