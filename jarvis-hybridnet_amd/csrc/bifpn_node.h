@@ -20,7 +20,8 @@ struct NodeArgs {
   int blds = 0;            // pointwise weights staged in LDS behind the operand tile
   int alias = 0;           // operand tile written over the halo tile (single channel chunk)
   float* y_pool = nullptr; // row-streaming form, two inputs: also the 2x2-max-pooled raw output [N][H/2][W/2][cout_p]
-  int rows = -1;           // row-streaming form (bifpn_rows.hip): 1 wherever the shape allows, 0 never, -1 by launch size
+  int rows = -1;           // row-streaming form (bifpn_rows.hip): 1 wherever the shape allows, 0 never, -1 by launch size,
+                           // 2 = the workgroup form with 8-row segments (wide pyramids, time batches below 8)
   int abl = 0;             // ablation bits for timing experiments (0 in production)   // cf = channels per halo chunk (multiple of 4)
 };
 

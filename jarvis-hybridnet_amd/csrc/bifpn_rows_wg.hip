@@ -28,13 +28,13 @@ namespace {
 constexpr int kWPX18 = 18;                         // ring row width: 16 pixels + the depthwise halo
 template <int RC>
 struct RowWgGeo {
-  static constexpr int NW = RC / 16;               // waves per workgroup = channel groups = output column blocks
+  static constexpr int NW = (RC + 15) / 16;        // waves per workgroup = channel groups = output column blocks
   static constexpr int K8 = RC / 8;
   static constexpr int RSA = RC + 4;               // operand-block row stride (floats): 16 rows on distinct banks
   static constexpr int ROWB = kWPX18 * RC * 4;     // bytes per ring row
   static constexpr int OPB = 16 * RSA * 4;         // bytes per operand block
   static constexpr size_t lds_bytes() { return (size_t)3 * ROWB + 2 * OPB; }
-  static_assert(RC % 16 == 0 && NW <= 16, "channel count of the workgroup row-streaming node");
+  static_assert(RC % 8 == 0 && NW <= 16, "channel count of the workgroup row-streaming node");
 };
 typedef float wf2 __attribute__((ext_vector_type(2)));
 typedef float wf4 __attribute__((ext_vector_type(4)));
@@ -54,6 +54,9 @@ void bifpn_rows_wg_kernel(const NodeArgs a, int seg_rows, int strips) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane & 3, sub = lane >> 2;         // channel quad inside the wave's 16 channels, pixel slot 0..15
   const int c = wave * 16 + q * 4;
+  // (88 channels = 5.5 groups: the last wave's quads 2, 3 and its output channels 88..95 do not exist)
+  const bool cq_ok = RC % 16 == 0 || c < RC;
+  const int cs = cq_ok ? c : 0;                    // a valid quad for the loads of per-channel constants
   const int sx = blockIdx.x % strips, seg = blockIdx.x / strips, n = blockIdx.y;
   const int ox0 = sx * 16, y_begin = seg * seg_rows, y_end = min(a.H, y_begin + seg_rows);
   const int mrow = lane & 15, kq = lane >> 4;
@@ -67,7 +70,7 @@ void bifpn_rows_wg_kernel(const NodeArgs a, int seg_rows, int strips) {
     if (a.st[k]) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const double* st = a.st[k] + ((size_t)n * RC + c + j) * kStatW;
+        const double* st = a.st[k] + ((size_t)n * RC + cs + j) * kStatW;
         const double mu = exact_read(st) * (double)a.inv_cnt[k];
         double var = exact_read(st + kLimbs) * (double)a.inv_cnt[k] - mu * mu;
         if (var < 0.0) var = 0.0;
@@ -84,11 +87,11 @@ void bifpn_rows_wg_kernel(const NodeArgs a, int seg_rows, int strips) {
   }
   wf4 dwr[9];                                      // depthwise weights of this lane's channel quad
 #pragma unroll
-  for (int t = 0; t < 9; ++t) dwr[t] = *reinterpret_cast<const wf4*>(a.dw + t * RC + c);
+  for (int t = 0; t < 9; ++t) dwr[t] = *reinterpret_cast<const wf4*>(a.dw + t * RC + cs);
   // pointwise weights of output column block `wave` for all RC / 8 channel steps (packed as for bifpn_rows.hip:
   // weights are the A operand, pixels the B operand, so a lane's accumulator is four consecutive channels
   // 16 wave + 4 (lane >> 4) .. + 3 of pixel lane & 15)
-  constexpr int NCB = RC / 16;
+  constexpr int NCB = GEO::NW;
   wf2 bw[K8];
 #pragma unroll
   for (int k8 = 0; k8 < K8; ++k8)
@@ -114,7 +117,7 @@ void bifpn_rows_wg_kernel(const NodeArgs a, int seg_rows, int strips) {
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int px = it * 16 + sub, ix = ox0 - 1 + px;
-    has[it] = px < kWPX18;
+    has[it] = px < kWPX18 && cq_ok;
     const bool ok = has[it] && (unsigned)ix < (unsigned)a.W;
     msk[it] = ok ? 1.f : 0.f;
 #pragma unroll
@@ -129,7 +132,8 @@ void bifpn_rows_wg_kernel(const NodeArgs a, int seg_rows, int strips) {
   const int ard = kOpOff + (mrow * RSA) * 4 + kq * 8;           // + operand buffer + channel step (imm)
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
       a.y + (size_t)n * a.H * a.W * a.cout_p, 0, (int)((size_t)a.H * a.W * a.cout_p * 4), 0x00020000);
-  const int yoff = ((ox0 + mrow) * a.cout_p + wave * 16 + kq * 4) * 4;
+  const bool co_ok = RC % 16 == 0 || wave * 16 + kq * 4 < RC;          // (cout_p == RC: checked by the launcher)
+  const int yoff = co_ok ? ((ox0 + mrow) * a.cout_p + wave * 16 + kq * 4) * 4 : (int)0x80000000;
   // POOL: the node also writes MaxPool2d(2, 2) of its raw output (max commutes with the monotone InstanceNorm map,
   // the pooled tensor keeps this node's statistics).  Horizontal max: the neighbour pixel is lane ^ 1 (one DPP
   // move); vertical: the even row's maxima wait in registers for the odd row.  Lanes of even pixels own the pixel.
@@ -138,7 +142,7 @@ void bifpn_rows_wg_kernel(const NodeArgs a, int seg_rows, int strips) {
   if (POOL) {
     rp = __builtin_amdgcn_make_buffer_rsrc(a.y_pool + (size_t)n * (a.H >> 1) * (a.W >> 1) * a.cout_p, 0,
                                            (int)((size_t)(a.H >> 1) * (a.W >> 1) * a.cout_p * 4), 0x00020000);
-    if (!(mrow & 1)) pbase = (((ox0 + mrow) >> 1) * a.cout_p + wave * 16 + kq * 4) * 4;
+    if (!(mrow & 1) && co_ok) pbase = (((ox0 + mrow) >> 1) * a.cout_p + wave * 16 + kq * 4) * 4;
   }
   wf4 park = (wf4){0.f, 0.f, 0.f, 0.f};
   wf4 raw[NIN][NIT];
@@ -213,7 +217,7 @@ void bifpn_rows_wg_kernel(const NodeArgs a, int seg_rows, int strips) {
         for (int dx = 0; dx < 3; ++dx)
           d = __builtin_elementwise_fma(*reinterpret_cast<const wf4*>(src + dx * RC * 4), dwr[dy * 3 + dx], d);
       }
-      *reinterpret_cast<wf4*>(smem + adst + kBuf) = d;
+      if (cq_ok) *reinterpret_cast<wf4*>(smem + adst + kBuf) = d;
     }
     lds_barrier();                                   // every channel group of the operand block is written
     // ---- pointwise 1x1: 16 output channels x 16 pixels x RC channels on the matrix cores --------------------
@@ -267,7 +271,7 @@ void bifpn_rows_wg_kernel(const NodeArgs a, int seg_rows, int strips) {
     for (int i = 0; i < 4; ++i) {
       const float t1 = row_sum(s1[i]), t2 = row_sum(s2[i]);
       const int ch = wave * 16 + kq * 4 + i;
-      if (mrow == 0) stat_add(a.stats + ((size_t)n * a.cout_p + ch) * kStatW, t1, t2);
+      if (mrow == 0 && co_ok) stat_add(a.stats + ((size_t)n * a.cout_p + ch) * kStatW, t1, t2);
     }
   }
 }
@@ -275,15 +279,18 @@ void bifpn_rows_wg_kernel(const NodeArgs a, int seg_rows, int strips) {
 // Shapes of the workgroup form (the channel count is checked by the caller, bifpn_rows_eligible): as many output
 // channels as input channels, no padding in either.
 bool bifpn_rows_wg_shape_ok(const NodeArgs& a) {
-  return a.Cp == 160 && a.cout_p == a.Cp && a.cout_p16 == a.Cp;
+  return (a.Cp == 160 || a.Cp == 88) && a.cout_p == a.Cp && a.cout_p16 == (a.Cp + 15) / 16 * 16;
 }
 
-int launch_bifpn_rows_wg(const NodeArgs& a, hipStream_t s) {
-  constexpr int RC = 160;
+template <int RC>
+static int launch_rows_wg_rc(const NodeArgs& a, hipStream_t s) {
   const int strips = a.W / 16;
-  // Rows per workgroup: a function of the node ONLY (the float partial sums of the statistics are taken per strip
-  // segment: bit-equal results for any number of images per launch), as in bifpn_rows.hip.
+  // Rows per workgroup: a function of the node and of the predictor's time-batch CLASS only (the float partial sums
+  // of the statistics are taken per strip segment: bit-equal results for any number of images per launch), as in
+  // bifpn_rows.hip.  a.rows == 2 (time batches below 8, the single-frame caller among them: few images, latency
+  // matters): 8-row segments, so that a 64 x 64 level of 12 images is 384 workgroups of ten rows each.
   int seg_rows = JH_ENV_KNOB("JH_NODE_SEG") > 0 ? JH_ENV_KNOB("JH_NODE_SEG")
+                 : a.rows == 2 ? 8
                  : (a.n_in == 2 || a.mode[1] == FUSE_SAME ? std::max(8, a.H / 2) : (a.H >= 64 ? 16 : 8));
   seg_rows = (seg_rows + 1) & ~1;
   if (seg_rows > a.H) seg_rows = a.H;
@@ -311,6 +318,11 @@ int launch_bifpn_rows_wg(const NodeArgs& a, hipStream_t s) {
 #undef JH_ROWS
   JH_CHECK_HIP(hipGetLastError());
   return 0;
+}
+
+int launch_bifpn_rows_wg(const NodeArgs& a, hipStream_t s) {
+  if (a.Cp == 88) return launch_rows_wg_rc<88>(a, s);
+  return launch_rows_wg_rc<160>(a, s);
 }
 
 }  // namespace jh

@@ -392,14 +392,17 @@ int EffTrackPlan::node(const ParamMap& pm, const std::string& cp, int n_in, cons
   a.dw = dwd; a.pw = cw.w; a.bias = cw.bias; a.y = out->a.p;
   a.N = like.N; a.H = like.H; a.W = like.W; a.Cp = like.Cp;
   a.cout_p = out->a.Cp; a.cout_p16 = cw.cout_p16;
-  a.rows = node_rows;
+  // (time batches below 8 -- node_rows 0: the 56-channel pyramid keeps the tile form, 13 us per node for one frame
+  //  set; the wide pyramids take the workgroup row form with short segments, csrc/bifpn_rows_wg.hip: their tile path
+  //  costs 35-130 us per node whatever the level)
+  a.rows = node_rows == 0 && like.Cp >= 88 ? 2 : node_rows;
   if (pooled) {
     // the row-streaming two-input form can write the 2x2-max-pooled raw output on the side (bifpn_rows.hip): the
     // bottom-up node of the next level then reads a same-resolution tensor with THIS node's statistics
     pooled->a = Act{};
     // (160 channels, csrc/bifpn_rows_wg.hip: also the node with three same-level inputs, so the bottom-up pass stays in
     //  the row-streaming form one level further down)
-    const bool same3 = n_in == 3 && modes[1] == FUSE_SAME && modes[2] == FUSE_SAME && like.Cp == 160;
+    const bool same3 = n_in == 3 && modes[1] == FUSE_SAME && modes[2] == FUSE_SAME && (like.Cp == 160 || a.rows == 2);
     if ((n_in == 2 || same3) && act == ACT_SILU && out->a.Cp == like.Cp && like.H % 2 == 0 && bifpn_rows_eligible(a)) {
       if (new_act(like.N, 1, like.H / 2, like.W / 2, cout, &pooled->a)) return 1;
       pooled->st = (long)st; pooled->inv = out->inv; pooled->act = out->act;

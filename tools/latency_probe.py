@@ -3,7 +3,7 @@ configs[2]: wall time per forward (graph replay and plain launches) and, from on
 pass, the per-launch HIP-event durations in launch order -- what the 150 launches of one
 forward cost on the GPU when each covers a single frame set.
 
-    python3 tools/latency_probe.py [T]        (also the command for rocprofv3 --kernel-trace)
+    python3 tools/latency_probe.py [T [model size]]        (also the command for rocprofv3 --kernel-trace)
 """
 import os
 import sys
@@ -17,12 +17,13 @@ from jarvis_hybridnet_amd import synthetic as S  # noqa: E402
 from jarvis_hybridnet_amd._predictor import NativePredictor  # noqa: E402
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+SIZE = sys.argv[2] if len(sys.argv) > 2 else "small"
 C, W, H, J = 12, 1280, 1024, 23
 calib = S.ring_calibration(C, W, H, 1800.0)
-sd_c, sd_h = S.efficienttrack_weights("small", 1, 50), S.hybridnet_weights("small", J, 51)
+sd_c, sd_h = S.efficienttrack_weights(SIZE, 1, 50), S.hybridnet_weights(SIZE, J, 51)
 fr = torch.stack([S.blob_frames(calib, W, H, J, 52 + i)[0] for i in range(T)]).cuda()
 p = NativePredictor(sd_c, sd_h, num_cameras=C, num_joints=J, center_size=256, bbox=256, roi_cube_size=128,
-                    grid_spacing=2, img_h=H, img_w=W, mean=S.MEAN, std=S.STD, time_batch=T)
+                    grid_spacing=2, img_h=H, img_w=W, mean=S.MEAN, std=S.STD, time_batch=T, center_model=SIZE, kp_model=SIZE)
 p.set_calibration(*[t.cuda() for t in calib])
 out = None
 for mode in ((True, False) if p.Cloc == p.C else (False,)):
