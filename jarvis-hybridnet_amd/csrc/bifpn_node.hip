@@ -593,6 +593,8 @@ int launch_bifpn_node(const NodeArgs& args, hipStream_t s) {
   //  itself too small for the row form)
   if (a.n_in == 3 && m1 == FUSE_SAME && m2 == FUSE_SAME)
     return launch_node_variant<3, FUSE_SAME, FUSE_SAME, FUSE_SAME>(a, lds, s);
+  // (... and its two-input sibling at the coarsest level: P7 from P7_in and the pooled P6 written by P6's row node)
+  if (a.n_in == 2 && m1 == FUSE_SAME) return launch_node_variant<2, FUSE_SAME, FUSE_SAME, 0>(a, lds, s);
   JH_REQUIRE(false, "unsupported BiFPN node variant");
 }
 

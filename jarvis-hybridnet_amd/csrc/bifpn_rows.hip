@@ -373,15 +373,22 @@ bool bifpn_rows_eligible(const NodeArgs& a) {
   if (a.Cp != 56 && !(a.Cp == 88 && JH_ENV_KNOB("JH_NODE_ROWS88") != 0) && !wg) return false;
   // (88 / 160 channels: also the 16-pixel-wide level -- one strip per image -- because the tile kernel's path for more
   //  than 64 channels is slow there, 0.10 ms per launch against 0.05; at 56 channels the tile kernel wins below 32 pixels)
-  if (a.cout_p16 != (a.Cp + 15) / 16 * 16 || a.W % 16 != 0 || a.W < (a.Cp >= 88 ? 16 : 32) || a.H < 16) return false;
-  if (a.mode[0] != FUSE_SAME) return false;
+  if (a.cout_p16 != (a.Cp + 15) / 16 * 16 || a.mode[0] != FUSE_SAME) return false;
+  if (wg) {
+    // the workgroup form masks the pixels past the row end of its last strip: every level down to 2 x 2 (the tile
+    // kernel's path for more than 64 channels costs 35-130 us per launch whatever the level)
+    if (a.W < 2 || a.H < 2) return false;
+  } else if (a.W % 16 != 0 || a.W < (a.Cp >= 88 ? 16 : 32) || a.H < 16) {
+    return false;
+  }
   if (a.rows < 0) {
     // (one wave per workgroup walking >= 10 rows: below ~2048 strips the chip is not filled and the tile form wins)
     const int min_wg = JH_ENV_KNOB("JH_NODE_ROWS_MINWG") > 0 ? JH_ENV_KNOB("JH_NODE_ROWS_MINWG") : 2048;
-    if ((a.W / 16) * ((a.H + 7) / 8) * a.N < min_wg) return false;
+    if (((a.W + 15) / 16) * ((a.H + 7) / 8) * a.N < min_wg) return false;
   }
-  if (a.n_in == 2) return a.mode[1] == FUSE_UP2;
-  return a.n_in == 3 && ((a.mode[1] == FUSE_UP2 && a.mode[2] == FUSE_UP4) ||
+  const bool up2_ok = a.W % 2 == 0 && a.H % 2 == 0, up4_ok = a.W % 4 == 0 && a.H % 4 == 0;
+  if (a.n_in == 2) return (a.mode[1] == FUSE_UP2 && up2_ok) || (wg && a.mode[1] == FUSE_SAME);
+  return a.n_in == 3 && ((a.mode[1] == FUSE_UP2 && a.mode[2] == FUSE_UP4 && up4_ok) ||
                          (a.mode[1] == FUSE_SAME && a.mode[2] == FUSE_SAME));
 }
 

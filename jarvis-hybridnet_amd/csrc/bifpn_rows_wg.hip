@@ -133,7 +133,11 @@ void bifpn_rows_wg_kernel(const NodeArgs a, int seg_rows, int strips) {
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
       a.y + (size_t)n * a.H * a.W * a.cout_p, 0, (int)((size_t)a.H * a.W * a.cout_p * 4), 0x00020000);
   const bool co_ok = RC % 16 == 0 || wave * 16 + kq * 4 < RC;          // (cout_p == RC: checked by the launcher)
-  const int yoff = co_ok ? ((ox0 + mrow) * a.cout_p + wave * 16 + kq * 4) * 4 : (int)0x80000000;
+  // (ragged last strip -- levels narrower than 16 pixels or not a multiple of 16: pixels past the row end are computed
+  //  from zero-padded input like any border pixel and dropped here: no store, no statistics)
+  const bool pok = ox0 + mrow < a.W;
+  const float pm = pok ? 1.f : 0.f;
+  const int yoff = co_ok && pok ? ((ox0 + mrow) * a.cout_p + wave * 16 + kq * 4) * 4 : (int)0x80000000;
   // POOL: the node also writes MaxPool2d(2, 2) of its raw output (max commutes with the monotone InstanceNorm map,
   // the pooled tensor keeps this node's statistics).  Horizontal max: the neighbour pixel is lane ^ 1 (one DPP
   // move); vertical: the even row's maxima wait in registers for the odd row.  Lanes of even pixels own the pixel.
@@ -142,7 +146,7 @@ void bifpn_rows_wg_kernel(const NodeArgs a, int seg_rows, int strips) {
   if (POOL) {
     rp = __builtin_amdgcn_make_buffer_rsrc(a.y_pool + (size_t)n * (a.H >> 1) * (a.W >> 1) * a.cout_p, 0,
                                            (int)((size_t)(a.H >> 1) * (a.W >> 1) * a.cout_p * 4), 0x00020000);
-    if (!(mrow & 1) && co_ok) pbase = (((ox0 + mrow) >> 1) * a.cout_p + wave * 16 + kq * 4) * 4;
+    if (!(mrow & 1) && co_ok && pok) pbase = (((ox0 + mrow) >> 1) * a.cout_p + wave * 16 + kq * 4) * 4;
   }
   wf4 park = (wf4){0.f, 0.f, 0.f, 0.f};
   wf4 raw[NIN][NIT];
@@ -230,8 +234,9 @@ void bifpn_rows_wg_kernel(const NodeArgs a, int seg_rows, int strips) {
     }
     // ---- bias, statistics (in registers across the strip), one 16-byte store ---------------------------------
     const wf4 v = ((wf4){acc0[0], acc0[1], acc0[2], acc0[3]} + (wf4){acc1[0], acc1[1], acc1[2], acc1[3]}) + b4;
-    s1 += v;
-    s2 = __builtin_elementwise_fma(v, v, s2);
+    const wf4 vm = v * (wf4){pm, pm, pm, pm};
+    s1 += vm;
+    s2 = __builtin_elementwise_fma(vm, v, s2);
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wu4, v), ry, yoff + y * a.W * a.cout_p * 4, 0, 0);
     if (POOL) {
       wf4 hm;
@@ -284,13 +289,15 @@ bool bifpn_rows_wg_shape_ok(const NodeArgs& a) {
 
 template <int RC>
 static int launch_rows_wg_rc(const NodeArgs& a, hipStream_t s) {
-  const int strips = a.W / 16;
+  const int strips = (a.W + 15) / 16;
   // Rows per workgroup: a function of the node and of the predictor's time-batch CLASS only (the float partial sums
   // of the statistics are taken per strip segment: bit-equal results for any number of images per launch), as in
-  // bifpn_rows.hip.  a.rows == 2 (time batches below 8, the single-frame caller among them: few images, latency
-  // matters): 8-row segments, so that a 64 x 64 level of 12 images is 384 workgroups of ten rows each.
+  // bifpn_rows.hip.  a.rows == 2 (time batches below 8, the single-frame caller among them: few images, a node is a
+  // latency chain of its rows): short segments -- measured per node with one 12-camera frame set, 88 / 160 channels,
+  // us: 64-row levels 16 rows 33 / 62 (8: 41 / 72, 4: 50 / 79, 32: 53 / 103); 32-row levels 4 rows 18 / 29 (8: 22 / 38,
+  // 2: 26 / 42); 16 rows and below 2 rows 13 / 21 (4: 15 / 26, 8: 21 / 37).
   int seg_rows = JH_ENV_KNOB("JH_NODE_SEG") > 0 ? JH_ENV_KNOB("JH_NODE_SEG")
-                 : a.rows == 2 ? 8
+                 : a.rows == 2 ? (a.H >= 64 ? 16 : (a.H >= 32 ? 4 : 2))
                  : (a.n_in == 2 || a.mode[1] == FUSE_SAME ? std::max(8, a.H / 2) : (a.H >= 64 ? 16 : 8));
   seg_rows = (seg_rows + 1) & ~1;
   if (seg_rows > a.H) seg_rows = a.H;
@@ -301,7 +308,10 @@ static int launch_rows_wg_rc(const NodeArgs& a, hipStream_t s) {
   hipLaunchKernelGGL((bifpn_rows_wg_kernel<RC, NIN, M1, M2, ACT, POOL>), grid, block, lds, s, a, seg_rows, strips)
   JH_REQUIRE(!a.y_pool || (a.act == ACT_SILU && a.H % 2 == 0 && (a.n_in == 2 || a.mode[1] == FUSE_SAME)),
              "workgroup row-streaming node: pooled output");
-  if (a.n_in == 2) {
+  if (a.n_in == 2 && a.mode[1] == FUSE_SAME) {       // (bottom-up node of the coarsest level: P7 from P7_in and pooled P6)
+    JH_REQUIRE(a.act == ACT_SILU && !a.y_pool, "workgroup row-streaming node: two same-level inputs");
+    JH_ROWS(2, FUSE_SAME, 0, ACT_SILU, false);
+  } else if (a.n_in == 2) {
     if (a.act == ACT_SILU && a.y_pool) JH_ROWS(2, FUSE_UP2, 0, ACT_SILU, true);
     else if (a.act == ACT_SILU) JH_ROWS(2, FUSE_UP2, 0, ACT_SILU, false);
     else if (a.act == ACT_NONE) JH_ROWS(2, FUSE_UP2, 0, ACT_NONE, false);

@@ -537,17 +537,32 @@ int EffTrackPlan::build(const ParamMap& pm, const std::string& pre, int size, in
       const Ref in[3] = {p4_in2, p4_up, p3_out};
       if (fnode("p4_w2", 3, in, m_dn3, p4_in2, "conv4_down", &p4_out)) return 1;
     }
-    if (p4_pool.a.p) {          // (160 channels: P4's bottom-up node wrote its pooled output too)
+    // the head reads p3, p4, p5 of the last cell only: its p6 / p7 outputs are dead
+    const bool more = cell + 1 < ss.cells;
+    Ref p5_pool, p6_pool;
+    if (p4_pool.a.p) {          // (wide pyramids: P4's bottom-up node wrote its pooled output too, and so on down)
       const Ref in[3] = {p5_in2, p5_up, p4_pool};
-      if (fnode("p5_w2", 3, in, m_same3, p5_in2, "conv5_down", &p5_out)) return 1;
+      if (fnode("p5_w2", 3, in, m_same3, p5_in2, "conv5_down", &p5_out, more ? &p5_pool : nullptr)) return 1;
     } else {
       const Ref in[3] = {p5_in2, p5_up, p4_out};
       if (fnode("p5_w2", 3, in, m_dn3, p5_in2, "conv5_down", &p5_out)) return 1;
     }
-    // the head reads p3, p4, p5 of the last cell only: its p6 / p7 outputs are dead
-    if (cell + 1 < ss.cells) {
-      { const Ref in[3] = {p6_in, p6_up, p5_out}; if (fnode("p6_w2", 3, in, m_dn3, p6_in, "conv6_down", &p6_out)) return 1; }
-      { const Ref in[2] = {p7_in, p6_out}; if (fnode("p7_w2", 2, in, m_dn2, p7_in, "conv7_down", &p7_out)) return 1; }
+    if (more) {
+      if (p5_pool.a.p) {
+        const Ref in[3] = {p6_in, p6_up, p5_pool};
+        if (fnode("p6_w2", 3, in, m_same3, p6_in, "conv6_down", &p6_out, &p6_pool)) return 1;
+      } else {
+        const Ref in[3] = {p6_in, p6_up, p5_out};
+        if (fnode("p6_w2", 3, in, m_dn3, p6_in, "conv6_down", &p6_out)) return 1;
+      }
+      if (p6_pool.a.p) {
+        const int m_same2[2] = {FUSE_SAME, FUSE_SAME};
+        const Ref in[2] = {p7_in, p6_pool};
+        if (fnode("p7_w2", 2, in, m_same2, p7_in, "conv7_down", &p7_out)) return 1;
+      } else {
+        const Ref in[2] = {p7_in, p6_out};
+        if (fnode("p7_w2", 2, in, m_dn2, p7_in, "conv7_down", &p7_out)) return 1;
+      }
     }
     p3 = p3_out; p4 = p4_out; p5 = p5_out; p6 = p6_out; p7 = p7_out;
   }

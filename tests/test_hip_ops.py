@@ -217,6 +217,14 @@ NODE_CASES = [  # (C, Cout, H, W, modes, act, n): the node shapes of the small /
     (160, 160, 32, 32, (0, 0, 0), 2, 256),  # P4 bottom-up with three same-level inputs
     (160, 160, 48, 32, (0, 1), 2, 192),     # ragged height
     (160, 160, 16, 16, (0, 1), 2, 2048),    # P5 top-down: one strip per image
+    # ... and the levels narrower than a strip / not a multiple of 16 pixels (pixels past the row end masked)
+    (160, 160, 8, 8, (0, 1), 2, 2048),      # P6 top-down
+    (160, 160, 8, 8, (0, 0, 0), 2, 2048),   # P6 bottom-up with P5's pooled output
+    (160, 160, 4, 4, (0, 0), 2, 4096),      # P7 bottom-up: two same-level inputs (P7_in, pooled P6)
+    (160, 160, 2, 2, (0, 0), 2, 4096),      # ... of a 128-pixel crop
+    (160, 160, 24, 24, (0, 1), 2, 512),     # 192-pixel crops: P4 is 24 wide (one full and one half strip)
+    (160, 160, 24, 40, (0, 1, 2), 0, 384),  # three strips, the last one half empty; x1 / x2 / x4 inputs
+    (56, 56, 4, 4, (0, 0), 2, 3),           # the tile kernel's two-same-input variant (fallback of the above)
 ]
 
 
