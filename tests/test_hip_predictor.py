@@ -267,7 +267,8 @@ def test_sharded_stages_emulated_two_ranks(T):
                                                for i in range(T - 1)]))
     common = dict(num_cameras=C, num_joints=J, center_size=c["center_size"], bbox=c["bbox"],
                   roi_cube_size=c["roi"], grid_spacing=c["spacing"], img_h=c["H"], img_w=c["W"],
-                  mean=S.MEAN, std=S.STD, time_batch=T)
+                  mean=S.MEAN, std=S.STD, time_batch=T, center_model=c.get("size", "small"),
+                  kp_model=c.get("size", "small"))
     dev = [cuda(t) for t in calib]
     full = NativePredictor(inp["sd_center"], inp["sd_hybrid"], **common)
     full.set_calibration(*dev)
@@ -395,7 +396,8 @@ def _sharded_emulated(tag, world, T, mode, golden):
                                                for t in range(1, T)]))
     common = dict(num_cameras=C, num_joints=J, center_size=c["center_size"], bbox=c["bbox"],
                   roi_cube_size=c["roi"], grid_spacing=c["spacing"], img_h=c["H"], img_w=c["W"],
-                  mean=S.MEAN, std=S.STD, time_batch=T)
+                  mean=S.MEAN, std=S.STD, time_batch=T, center_model=c.get("size", "small"),
+                  kp_model=c.get("size", "small"))
     dev = [cuda(t) for t in calib]
     full = NativePredictor(inp["sd_center"], inp["sd_hybrid"], **common)
     full.set_calibration(*dev)
@@ -457,6 +459,14 @@ def test_sharded_cfg5_eight_ranks(mode, golden):
     per rank over EIGHT emulated ranks, T = 8 frame sets (one 3D frame per rank in the frame-sharded modes; the
     time-batch class whose P3 / P4 BiFPN nodes run in the row-streaming form)."""
     _sharded_emulated("cfg5", 8, 8, mode, golden)
+
+
+@pytest.mark.parametrize("tag,world,T", [("cfg3_medium", 2, 2), ("cfg3_large", 4, 4)])
+def test_sharded_wide_models(tag, world, T, golden):
+    """The medium / large models camera-sharded at a time batch below 8: their BiFPN nodes run the workgroup row form
+    with short segments there (csrc/bifpn_rows_wg.hip), whose segmentation -- and with it every partial sum of the
+    statistics -- must not depend on how many cameras a rank owns."""
+    _sharded_emulated(tag, world, T, "alltoall", golden)
 
 
 def test_center3d_truncation_seed_sweep():
