@@ -1,4 +1,4 @@
-// Fused BiFPN node, row-streaming form for the WIDE pyramids (160 channels: the large model; round 4).
+// Fused BiFPN node, row-streaming form for the WIDE pyramids (160 channels: the large model; 88: medium; round 4).
 //
 // Same function and the same walk as bifpn_rows.hip (fusion of 2-3 inputs with InstanceNorm on load, activation,
 // depthwise 3x3, pointwise 1x1 + bias, statistics of the output; jarvis/efficienttrack/model.py:309-353 +
@@ -16,6 +16,15 @@
 //     pairs), bias + statistics + one 16-byte store; the 2 x 2 max-pooled output is carried in registers between the
 //     two halves of the unrolled row loop, so every variant can write it.
 // One workgroup (10 waves at 160 channels, <= 168 registers) per CU; 55.5 KB of LDS.
+//
+// Also (round 4, single-frame latency of the medium / large models):
+//   * 88 channels = 5.5 channel groups: six waves, the last one's quads 2, 3 and output channels 88..95 masked.  At
+//     bench scale one wave per strip (bifpn_rows.hip) is the faster form there (0.49 against 0.67 ms per P3 node);
+//     this form serves the 88-channel pyramid at time batches below 8 only (NodeArgs::rows == 2),
+//   * the last strip of a row masks the pixels past the row end (no store, no statistics): every level down to
+//     2 x 2 and widths that are not multiples of 16 qualify,
+//   * rows == 2 picks short segments (a node is a latency chain of its rows when there are only a few images),
+//   * a variant with two same-level inputs (P7's bottom-up node fed by P6's pooled output).
 #include <algorithm>
 #include <type_traits>
 
