@@ -36,6 +36,11 @@ REPRO_CASES = {
     # the geometry the reference ships (projects/Example_Project/config.yaml:36-37: ROI_CUBE_SIZE 144,
     # GRID_SPACING 2 => G = 72, not a multiple of 16; repro_layer.py:18-19)
     "ex72": (12, 23, 72, 2, 256, 1280, 1024, 1800.0, 15),
+    # active crop clamps (jarvis3D.py:163-166 ahead of repro_layer.py:65-68): a long focal length pushes the subject's
+    # projection past the crop bounds, so the clamped crop centre is far from it and most voxels of those cameras
+    # fall outside the crop (the asymmetric index clamp decides them).  make_golden asserts the clamp counts.
+    "cfg2_edge": (4, 23, 48, 2, 256, 640, 512, 6000.0, 29),
+    "cfg3_edge": (12, 23, 64, 2, 256, 1280, 1024, 9000.0, 29),
 }
 
 # tag -> (J, G, weight seed, input seed)
@@ -96,6 +101,30 @@ PREDICTOR_CASES = {
     "cfg3_large": dict(C=12, J=23, roi=128, spacing=2, bbox=256, center_size=256,
                        W=1280, H=1024, focal=1800.0, cseed=71, hseed=72, fseed=53,
                        size="large"),
+    # --- the reference's detection edge cases (jarvis3D.py:153-160: `maxvals > 50` strict, `>= 2` decides, cameras
+    # below the threshold still enter reconstructPoint with their small weight, utils/reprojection.py:83).
+    # deconv_std scales the centre heat maps so the per-camera maxima straddle 50; seeds found with
+    # tools/edge_case_scout.py, n_detect asserted by make_golden.py ---
+    "cfg2_partial": dict(C=4, J=23, roi=96, spacing=2, bbox=256, center_size=256,
+                         W=640, H=512, focal=900.0, cseed=50, hseed=51, fseed=53,
+                         deconv_std=0.2526, n_detect=2),
+    "cfg2_one": dict(C=4, J=23, roi=96, spacing=2, bbox=256, center_size=256,
+                     W=640, H=512, focal=900.0, cseed=50, hseed=51, fseed=53,
+                     deconv_std=0.2419, n_detect=1, expect_none=True),
+    "cfg3_partial": dict(C=12, J=23, roi=128, spacing=2, bbox=256, center_size=256,
+                         W=1280, H=1024, focal=1800.0, cseed=50, hseed=51, fseed=52,
+                         deconv_std=0.2206, n_detect=7),
+    # --- active crop clamps (jarvis3D.py:163-166): long focal lengths push the centre's projection past
+    # [bbox/2, W - bbox/2] x [bbox/2, H - bbox/2]; `clamps` = cameras clamped at (x low, x high, y low, y high),
+    # asserted by make_golden.py ---
+    "cfg2_edge": dict(C=4, J=23, roi=96, spacing=2, bbox=256, center_size=256,
+                      W=640, H=512, focal=3600.0, cseed=50, hseed=51, fseed=61, clamps=(2, 2, 1, 0)),
+    "cfg2_edge_b": dict(C=4, J=23, roi=96, spacing=2, bbox=256, center_size=256,
+                        W=640, H=512, focal=3600.0, cseed=50, hseed=51, fseed=65, clamps=(2, 2, 0, 2)),
+    "cfg3_edge": dict(C=12, J=23, roi=128, spacing=2, bbox=256, center_size=256,
+                      W=1280, H=1024, focal=9000.0, cseed=50, hseed=51, fseed=52, clamps=(2, 2, 0, 2)),
+    "cfg3_edge_b": dict(C=12, J=23, roi=128, spacing=2, bbox=256, center_size=256,
+                        W=1280, H=1024, focal=10800.0, cseed=50, hseed=51, fseed=78, clamps=(3, 3, 10, 0)),
 }
 
 

@@ -183,6 +183,21 @@ def case_reprojection():
         print(tag, "ok", tuple(ref_vol.shape), "max %.1f  frac>1 %.3f" %
               (float(ref_vol.max()), frac))
         assert frac > 0.01, "degenerate reprojection case"
+        if tag.endswith("_edge"):
+            # the crop clamp is active: the subject's true projection lies outside the clamped crop centre's
+            # reach for several cameras, and a large share of those cameras' voxels take a border index
+            uv = torch.from_numpy(S.project(cases.subject_geometry(C, W, H, focal, bbox, seed)[3][None]
+                                            .double().numpy(), inp["cam"][0], inp["intr"][0], inp["dist"][0]))[:, 0]
+            chm = inp["center_hm"][0]
+            nx = int((uv[:, 0].int() != chm[:, 0]).sum())
+            ny = int((uv[:, 1].int() != chm[:, 1]).sum())
+            col, row = ref_idx % hs, ref_idx // hs
+            border = ((col == 0) | (col == hs - 1) | (row == 0) | (row == hs - 1)).float().flatten(1).mean(1)
+            print(tag, "cameras clamped in x %d, in y %d; per-camera share of border indices" % (nx, ny),
+                  [round(float(b), 3) for b in border])
+            assert nx >= 2 and ny >= 1 and float(border.max()) > 0.3
+            out[tag + ".clamped_xy"] = np.array([nx, ny], dtype=np.int64)
+            out[tag + ".border_share"] = border.numpy()
     save("reprojection", out)
 
 
@@ -315,10 +330,15 @@ def case_predictor():
                 bbox=c["bbox"], roi_cube_size=c["roi"],
                 grid_spacing=c["spacing"], mean=S.MEAN, std=S.STD, chunk=5,
                 center_model=size, kp_model=size, intermediates=inter)
+        if "n_detect" in c:
+            assert inter["n_detect"] == c["n_detect"], (tag, inter["n_detect"])
         if c.get("expect_none"):
             assert pts is None and conf is None and opts is None
             out[tag + ".none"] = np.int64(1)
             out[tag + ".n_detect"] = np.int64(inter["n_detect"])
+            out[tag + ".maxvals"] = inter["maxvals"].numpy()
+            meta[tag] = dict(n_detect=inter["n_detect"],
+                             maxvals_255=[round(float(v) * 255, 3) for v in inter["maxvals"].flatten()])
             print(tag, "ok (None path, n_detect=%d)" % inter["n_detect"])
             continue
         must_equal(pts, opts, tag + ".points3D")
@@ -337,9 +357,20 @@ def case_predictor():
         rp = O.reproject_point(c3.unsqueeze(0), inp["cam"], inp["intr"], inp["dist"])
         fr = (rp - rp.trunc()).abs()
         mr = torch.minimum(fr, 1 - fr).min().item()
+        # which cameras the crop clamp (jarvis3D.py:163-166) moved: the reference's own centerHMs against the
+        # unclamped integer reprojection of its centre
+        raw = rp.int()
+        hw = c["bbox"] // 2
+        clamps = (int((raw[:, 0] < hw).sum()), int((raw[:, 0] > c["W"] - hw).sum()),
+                  int((raw[:, 1] < hw).sum()), int((raw[:, 1] > c["H"] - hw).sum()))
+        assert int((raw != seen["center_hm"]).any(1).sum()) == int(((raw[:, 0] < hw) | (raw[:, 0] > c["W"] - hw) |
+                                                                  (raw[:, 1] < hw) | (raw[:, 1] > c["H"] - hw)).sum())
+        if "clamps" in c:
+            assert clamps == tuple(c["clamps"]), (tag, clamps)
         meta[tag] = dict(argmax_margin=margin, center3d_int_margin=m3,
                          center_hm_int_margin=mr, n_detect=inter["n_detect"],
-                         center3d=c3.tolist())
+                         center3d=c3.tolist(), clamped_xlo_xhi_ylo_yhi=list(clamps),
+                         maxvals_255=[round(float(v) * 255, 3) for v in inter["maxvals"].flatten()])
         print(tag, "margins", meta[tag])
         assert margin > 1e-3 and m3 > 2e-3 and mr > 2e-3, "fragile case: change seed"
         assert float(c3.abs().max()) < 1e4

@@ -44,13 +44,20 @@ def test_hybridnet_backbone(tag, golden):
     check_summary(g, tag + ".heatmap_final", fin.cpu(), rtol=1e-3, atol=1e-3)
 
 
-@pytest.mark.parametrize("tag", ["cfg2", "cfg3", "cfg2_none", "cfg2_u8", "cfg5", "ex72", "cfg3_medium", "cfg3_large"])
+EDGE_TAGS = ["cfg2_partial", "cfg2_one", "cfg3_partial", "cfg2_edge", "cfg2_edge_b", "cfg3_edge", "cfg3_edge_b"]
+
+
+@pytest.mark.parametrize("tag", ["cfg2", "cfg3", "cfg2_none", "cfg2_u8", "cfg5", "ex72", "cfg3_medium", "cfg3_large"]
+                         + EDGE_TAGS)
 def test_predictor3d(tag, golden):
     """JarvisPredictor3D.forward vs the imported reference's output on the same input
     (tests/golden/predictor.npz).  ex72 = the geometry the reference ships (Example_Project: 72^3 grid, V2V at
     36^3 / 18^3); cfg3_medium = configs[2] with the reference's default model size.  cfg2_u8: the HIP path is fed the uint8 BGR bytes
     (forward_uint8), the reference the driver's conversion of the same bytes
-    (predict3D.py:79-80).  cfg5 = BASELINE configs[4]: 16 cameras, 30 keypoints, 96^3."""
+    (predict3D.py:79-80).  cfg5 = BASELINE configs[4]: 16 cameras, 30 keypoints, 96^3.
+    *_partial / cfg2_one: 1 <= n_detect < C (jarvis3D.py:153-160: strict `> 50`, `>= 2` decides, the cameras below
+    the threshold still weigh into reconstructPoint); *_edge: the crop clamp of jarvis3D.py:163-166 moves several
+    cameras' crop centres (lower and upper bound, x and y: tests/golden/predictor_meta.json)."""
     from jarvis_hybridnet_amd.prediction.jarvis3D import JarvisPredictor3D
     c = cases.PREDICTOR_CASES[tag]
     inp = cases.predictor_inputs(tag)
@@ -63,6 +70,13 @@ def test_predictor3d(tag, golden):
     torch.cuda.synchronize()
     g = golden("predictor")
     dbg = pred.native(c["H"], c["W"]).debug("cuda")
+    if "n_detect" in c:
+        assert int(g[tag + ".n_detect"]) == c["n_detect"]
+        # the detection count the kernel acted on: maxima strictly above 50 (det[..., 2] holds the raw maximum;
+        # the fixture's maxvals are the reference's maxvals / 255)
+        n_hip = int((dbg["det"][0, :, 2].cpu() > 50).sum())
+        assert n_hip == c["n_detect"]
+        assert max_err(dbg["det"][0, :, 2].cpu() / 255., torch.from_numpy(g[tag + ".maxvals"]).flatten()) < 1e-5
     if c.get("expect_none"):
         assert pts is None and conf is None
         return
@@ -80,7 +94,8 @@ def test_predictor3d(tag, golden):
     assert ec < 1e-4
 
 
-@pytest.mark.parametrize("tag", ["ex72", "cfg3", "cfg3_medium", "cfg3_large"])
+@pytest.mark.parametrize("tag", ["ex72", "cfg3", "cfg3_medium", "cfg3_large", "cfg3_partial", "cfg3_edge",
+                                 "cfg2_partial", "cfg2_edge"])
 def test_predictor3d_time_batch_8_vs_fixture(tag, golden):
     """The time_batch >= 8 class (row-streaming BiFPN nodes: the form bench.py times) held to the REFERENCE fixture
     directly: frame 0 of an 8-frame-set call is the fixture case; the other seven are distinct subjects and

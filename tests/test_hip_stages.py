@@ -86,7 +86,7 @@ def test_v2v_and_tail(tag, golden):
     assert (pts.cpu() - torch.from_numpy(g[tag + ".points"])).abs().max() < 1e-3
 
 
-@pytest.mark.parametrize("tag", ["tiny", "cfg2", "cfg3", "cfg5", "ex72"])
+@pytest.mark.parametrize("tag", ["tiny", "cfg2", "cfg3", "cfg5", "ex72", "cfg2_edge", "cfg3_edge"])
 def test_reprojection(tag, golden):
     from types import SimpleNamespace as NS
     from jarvis_hybridnet_amd.hybridnet.repro_layer import ReprojectionLayer

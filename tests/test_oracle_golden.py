@@ -37,7 +37,7 @@ def test_efficienttrack(golden, tag):
     check_summary(g, tag + ".res2", r2, **TOL)
 
 
-@pytest.mark.parametrize("tag", ["tiny", "cfg2", "cfg3"])
+@pytest.mark.parametrize("tag", ["tiny", "cfg2", "cfg3", "cfg2_edge"])
 def test_reprojection(golden, tag):
     C, J, G, spacing = cases.REPRO_CASES[tag][:4]
     inp = cases.repro_inputs(tag)
@@ -119,7 +119,8 @@ def test_hybridnet(golden, tag):
     check_summary(g, tag + ".heatmaps_padded", hm, **TOL)
 
 
-@pytest.mark.parametrize("tag", ["cfg2", "cfg2_none", "cfg2_u8", "cfg5", "ex72", "cfg3_medium", "cfg3_large"])
+@pytest.mark.parametrize("tag", ["cfg2", "cfg2_none", "cfg2_u8", "cfg5", "ex72", "cfg3_medium", "cfg3_large",
+                                 "cfg2_partial", "cfg2_one", "cfg3_partial", "cfg2_edge", "cfg2_edge_b", "cfg3_edge"])
 def test_predictor(golden, tag):
     c = cases.PREDICTOR_CASES[tag]
     inp = cases.predictor_inputs(tag)
