@@ -63,7 +63,7 @@ CONFIGS = {
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_16x16x32_bf16 / 32x32x16, dense
 PEAK_HBM_GBS = 8000.0
-PMC_TRAFFIC = os.path.join("profiles", "r04_pmc_traffic.json")
+PMC_TRAFFIC = os.path.join("profiles", "r05_pmc_traffic.json")
 
 
 def usable_cores():
@@ -462,6 +462,11 @@ def main():
             if pmc.get("csrc_sha256") != csrc_sha256():
                 roof["traffic_note"] = "%s was measured on another csrc/ tree (sha256 %s...)" % (
                     PMC_TRAFFIC, str(pmc.get("csrc_sha256"))[:12])
+            elif (pmc.get("config", "cfg3"), pmc.get("model_size", "small")) != (args.config, size):
+                # several kernel names carry no shape (norm_apply, reproject_gather, ...): byte counts of another
+                # workload must not be reported under them
+                roof["traffic_note"] = "%s was measured on %s / %s, this run is %s / %s" % (
+                    PMC_TRAFFIC, pmc.get("config", "cfg3"), pmc.get("model_size", "small"), args.config, size)
             elif top["kernel"] in pmc:
                 e = pmc[top["kernel"]]
                 roof["traffic"] = e["hbm_bytes_per_launch"] * T_prof / pmc["time_batch"]
@@ -606,6 +611,31 @@ def main():
             # flips a few reprojection gather indices of the reference itself (DESIGN.md,
             # "reproducibility of the reference"); the pinned comparison is the next one.
             line["parity_max_abs_mm_vs_host_oracle"] = (res[0][0][0].cpu() - ref[0][0]).abs().max().item()
+            # ... and the one number that explains it: gather indices of THIS host's oracle that differ from the
+            # HIP path's (which equal the reference fixtures': tests/test_hip_stages.py::test_reprojection)
+            try:
+                from types import SimpleNamespace as NS
+                from jarvis_hybridnet_amd.hybridnet.repro_layer import ReprojectionLayer
+                inter = {}
+                with torch.no_grad():
+                    O.predictor3d_forward(sd_c, sd_h, distinct[0], *calib, intermediates=inter, **kw)
+                c3i, chm = inter["center3d"].int()[None], inter["center_hm"][None]
+                layer = ReprojectionLayer(NS(HYBRIDNET=NS(GRID_SPACING=c["spacing"], ROI_CUBE_SIZE=c["roi"],
+                                                          NUM_CAMERAS=c["C"]),
+                                             KEYPOINTDETECT=NS(BOUNDING_BOX_SIZE=c["bbox"])))
+                idx = layer.gather_indices(inter["heatmaps_padded"].to(dev), c3i.to(dev), chm.to(dev),
+                                           *[t[None] for t in calib_dev]).cpu()
+                grid = O.reprojection_grid(c["roi"], c["spacing"]) + c3i[0]
+                ridx = O.reprojection_indices(grid, *calib, chm[0], c["bbox"] // 2 + 2,
+                                              int(c["roi"] / c["spacing"]))[0]
+                line["host_oracle_index_flips"] = {
+                    "flips": int((idx != ridx).sum()), "of": int(ridx.numel()),
+                    "note": "gather indices of the oracle run on this host's CPU that differ from the HIP path's; torch's "
+                            "CPU kernels differ in the last bit between CPU models, each flip moves one voxel's tap by "
+                            "a pixel -- parity_max_abs_mm_vs_reference_fixture is the pinned comparison"}
+                del idx, layer
+            except Exception as e:                                  # noqa: BLE001
+                line["host_oracle_index_flips"] = {"error": repr(e)[:200]}
     if rank == 0 and world == 1 and size == "small" and args.config in ("cfg3", "cfg2", "cfg5", "ex72"):
         # frame 0 of this workload is a fixture case of tests/golden/predictor.npz, i.e. the
         # output of the imported upstream reference on the same input
@@ -732,13 +762,68 @@ def main():
                 mm.forward(frm)
             torch.cuda.synchronize()
             mdt = time.perf_counter() - t0
-            line["secondary"] = {"workload": c["workload"].replace("small/small", "medium/medium"),
-                                 "value": Tm * K * nst / mdt, "unit": "multi-view frames/s",
-                                 "ms_per_step": 1e3 * mdt / nst, "time_batch": Tm, "streams": K, "steps": nst}
+            sec = {"workload": c["workload"].replace("small/small", "medium/medium"),
+                   "value": Tm * K * nst / mdt, "unit": "multi-view frames/s",
+                   "ms_per_step": 1e3 * mdt / nst, "time_batch": Tm, "streams": K, "steps": nst, "dtype": "f32"}
+            # same measurement method as the headline: HIP events around every launch of one stream's time batch
+            mp = mm.preds[0]
+            N.profile(lambda: mp.forward(frm))
+            mrecs = []
+            for _ in range(3):
+                mrecs += N.profile(lambda: mp.forward(frm))
+            mtab, mtot, mex = kernel_table(mrecs, 3, 5)
+            sec["roofline"] = {k: mtab[0][k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac",
+                                                      "avg_launch_ms", "launches_per_step", "share_of_step")}
+            sec["roofline"]["traffic"] = None
+            sec["kernels"] = [{k: (round(v, 5) if isinstance(v, float) else v) for k, v in row.items()
+                               if k in ("kernel", "bound", "frac", "ms_per_step", "launches_per_step", "share_of_step")}
+                              for row in mtab]
+            sec["kernel_time_ms_per_time_batch"] = mtot
+            e2e = mex * K / (mdt / nst) / 1e12
+            sec["roofline_end_to_end"] = {"bound": "mfma", "achieved": e2e, "peak": PEAK_F32_MFMA_TFLOPS,
+                                          "unit": "TFLOP/s", "frac": e2e / PEAK_F32_MFMA_TFLOPS}
+            # frame 0 with the fixture's weights (tests/cases.py: cfg3_medium) against the imported reference's output
+            import numpy as np
+            gpath = os.path.join(ROOT, "tests", "golden", "predictor.npz")
+            if os.path.isfile(gpath):
+                from tests import cases as _cases
+                fc = _cases.PREDICTOR_CASES["cfg3_medium"]
+                fp = NativePredictor(S.efficienttrack_weights("medium", 1, fc["cseed"]),
+                                     S.hybridnet_weights("medium", c["J"], fc["hseed"]), **common_kw("medium", Tm))
+                fp.set_calibration(*calib_dev)
+                f0 = S.blob_frames(calib, c["W"], c["H"], c["J"], fc["fseed"])[0].to(dev)
+                fo = fp.forward(f0[None].expand(Tm, -1, -1, -1, -1).contiguous())
+                torch.cuda.synchronize()
+                gold = np.load(gpath)["cfg3_medium.points3D"]
+                sec["parity_max_abs_mm_vs_reference_fixture"] = float(np.abs(fo[0][0].cpu().numpy() - gold[0]).max())
+                del fp, fo
+            line["secondary"] = sec
             del mm, frm
         except Exception as e:                      # the secondary line never costs the headline
             line["secondary"] = {"error": repr(e)[:200]}
 
+    if sharded:
+        # ---- per-stage timeline of three pipelined submits on every rank (HIP events on the streams the stages
+        # run on, ms since the first submit): what DESIGN.md section 5's prediction of the overlap is checked against
+        # without a second run.  Collectives inside: every rank runs this, in the same order.
+        try:
+            sh.trace = []
+            torch.cuda.synchronize()
+            for _ in range(3):
+                sh.submit(fr)
+            sh.flush()
+            torch.cuda.synchronize()
+            t00 = sh.trace[0][1]
+            mine = [[lab, round(t00.elapsed_time(ev), 3)] for lab, ev in sh.trace]
+            sh.trace = None
+            allr = [None] * world
+            dist.all_gather_object(allr, mine)
+            line["stage_ms_per_rank"] = allr
+            line["rccl"] = {"world": world, "group_size": gs, "groups": n_groups,
+                            "version": ".".join(str(v) for v in torch.cuda.nccl.version()),
+                            "exchange": shs[0].exchange, "three_d": args.three_d}
+        except Exception as e:                                      # noqa: BLE001
+            line["stage_ms_per_rank"] = {"error": repr(e)[:200]}
     if sharded and (world > 1 or os.environ.get("JH_BENCH_SIDE_LEGS")) and not args.no_side_legs:
         line.update(side_legs(args, c, common, sd_c, sd_h, calib_dev, device_frames, dev, dist, world, T, gs,
                               make_sharded if args.three_d == "sharded" else None, fr, barrier))

@@ -114,6 +114,14 @@ class ShardedPredictor:
         self.cuda = torch.device(device).type == "cuda"
         self.s3d = torch.cuda.Stream(device=device) if self.cuda else None
         self._done3d = None                      # event: stage 3 of the last finished batch has read heat_recv
+        self.trace = None                        # list of (label, timing event) while a timeline is being recorded
+
+    def _mark(self, label):
+        """Timeline stamp on the current stream (bench.py: stage_ms_per_rank); free when no trace is recorded."""
+        if self.trace is not None and self.cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.trace.append((label, ev))
 
     def step(self, frames_local):
         """frames_local (T, Cloc, 3, H, W) -> points (T,J,3), conf (T,J), valid (T)."""
@@ -128,11 +136,16 @@ class ShardedPredictor:
     def submit(self, frames_local):
         """Start time batch i+1; returns the results of batch i (None on the first call)."""
         W = self.world
+        self._mark("submit")
         self.st.stage_center(frames_local, self.det_local)
+        self._mark("stage1_end")
         self.comm.all_gather_into_tensor(self.det_gather, self.det_local, group=self.group)
+        self._mark("det_gathered")
         prev = self._finish()
-        # det_gather is (W, T, Cl, 3): read in place, camera = source rank * Cl + local camera
+        # det_gather is (W, T, Cl, 3): read in place, camera = source rank * Cl + local camera.  heat_local is the
+        # SEND buffer of exchange(i): _finish() has made this stream wait for that exchange's completion.
         self.st.stage_keypoints_gathered(frames_local, self.det_gather, W, self.heat_local)
+        self._mark("stage2_end")
         if self._done3d is not None:
             # exchange(i+1) overwrites the receive buffer stage_3d(i) reads; the results returned above are
             # stream-ordered for the caller from here on too
@@ -145,6 +158,7 @@ class ShardedPredictor:
         else:
             self._pending = self.comm.all_gather_into_tensor(self.heat_recv, self.heat_local,
                                                              group=self.group, async_op=True)
+        self._mark("exchange_issued")
         return prev
 
     def flush(self):
@@ -169,6 +183,10 @@ class ShardedPredictor:
             res = self._finish_on_current_stream()
             self._done3d = torch.cuda.Event()
             self._done3d.record(self.s3d)
+        # exchange(i) has read its send buffer heat_local, which stage 2 of batch i+1 overwrites on the caller's
+        # stream next: an explicit dependency (the order of the collectives on the communicator implied it, but that
+        # is an implementation detail of ProcessGroupNCCL)
+        cur.wait_event(self._exchanged)
         for t in res:
             t.record_stream(cur)                 # allocated on the side stream, consumed on the caller's
         return res
@@ -177,16 +195,23 @@ class ShardedPredictor:
         W = self.world
         self._pending.wait()                     # the current stream waits for exchange(i)
         self._pending = None
+        if self.cuda:
+            self._exchanged = torch.cuda.Event()
+            self._exchanged.record()
+        self._mark("exchange_done")
         if self.three_d == "rank0":
             if self.rank == 0:
                 self._run_3d()
             # results of the whole time batch from rank 0 to everybody
             self.comm.broadcast(self.res_local, self._global_rank0(), group=self.group)
             self.comm.broadcast(self.valid_local, self._global_rank0(), group=self.group)
+            self._mark("results_end")
             return self._split(self.res_local.view(1, -1), self.valid_local)
         self._run_3d()
+        self._mark("stage3_end")
         self.comm.all_gather_into_tensor(self.res_all, self.res_local, group=self.group)
         self.comm.all_gather_into_tensor(self.valid_all, self.valid_local, group=self.group)
+        self._mark("results_end")
         return self._split(self.res_all.view(W, -1), self.valid_all)
 
     def _split(self, res, valid):

@@ -83,6 +83,7 @@ class FramePipeline:
     def rebind(self, submit, emit):
         """Start a new run on the same staging buffers (a driver call re-uses the pinned memory of the
         previous one: pinning gigabytes costs seconds)."""
+        self.quiesce()
         self.submit, self.emit = submit, emit
         self.group, self.fill, self.jobs = 0, 0, []
         self.inflight = []                      # (outputs, event, n_real) of submitted batches
@@ -91,6 +92,22 @@ class FramePipeline:
         # forward, waiting for the oldest batch's event, reading back + emitting rows
         self.stats = dict(fill_wait=0.0, submit=0.0, event_wait=0.0, emit=0.0, batches=0)
         return self
+
+    def quiesce(self):
+        """Nothing of an earlier run may still touch the staging buffers when a new run starts filling slot 0: a
+        run that ended in an exception (frame iterator, fill callable, submit) leaves pool jobs and enqueued
+        uploads / forwards behind.  Wait for the host-side jobs (their exceptions belong to the old run) and for the
+        events of the batches in flight; the copy stream's uploads precede those forwards."""
+        for j in getattr(self, "jobs", ()):
+            try:
+                j.result()
+            except Exception:                    # noqa: BLE001 -- reported by the run that raised it
+                pass
+        for _, ev, _ in getattr(self, "inflight", ()):
+            if ev is not None:
+                ev.synchronize()
+        if self.cuda and getattr(self, "copy_stream", None) is not None:
+            self.copy_stream.synchronize()
 
     # ---- host fill ---------------------------------------------------------------------------------
     def _copy_into(self, dst, src):
@@ -187,9 +204,12 @@ class DevicePipeline:
     """The same interface for frame sets that already live in HBM (CUDA tensors): no staging, the
     time batch is assembled on the device."""
 
-    def __init__(self, time_batch, submit, emit):
+    def __init__(self, time_batch, submit, emit, streams=1):
         self.T, self.submit, self.emit = int(time_batch), submit, emit
         self.group, self.frames_in = [], 0
+        self.keep = max(0, int(streams) - 1)    # batches left in flight behind the one just submitted
+        self.slots = self.keep + 1              # output-ring slots: one per batch that can be in flight
+        self.n, self.inflight = 0, []
 
     def push(self, frames):
         self.group.append(frames)
@@ -201,14 +221,23 @@ class DevicePipeline:
         real = len(self.group)
         x = torch.stack(self.group + [self.group[-1]] * (self.T - real))
         self.group = []
-        outs, ev = self.submit(x, 0)
-        if ev is not None:
-            ev.synchronize()
-        self.emit(tuple(o if not o.is_cuda else o.cpu() for o in outs), real)
+        # the slot's previous batch has been emitted: at most `keep` batches are in flight at this point
+        self.drain(self.keep)
+        outs, ev = self.submit(x, self.n % self.slots)
+        self.n += 1
+        self.inflight.append((outs, ev, real))
+
+    def drain(self, keep=0):
+        while len(self.inflight) > keep:
+            outs, ev, real = self.inflight.pop(0)
+            if ev is not None:
+                ev.synchronize()
+            self.emit(tuple(o if not o.is_cuda else o.cpu() for o in outs), real)
 
     def finish(self):
         if self.group:
             self._launch()
+        self.drain(0)
         return self.frames_in
 
 
@@ -231,7 +260,7 @@ def pipeline_for(owner, frames, time_batch, streams, submit, emit, frame_spec=No
     `frames` is a fill callable), cached on `owner` (the predictor) so that its pinned buffers are re-used by
     later driver calls."""
     if torch.is_tensor(frames) and frames.is_cuda:
-        return DevicePipeline(time_batch, submit, emit)
+        return DevicePipeline(time_batch, submit, emit, streams)
     if callable(frames):
         if frame_spec is None:
             raise ValueError("fill callables need frame_spec=(shape, dtype)")
@@ -244,6 +273,13 @@ def pipeline_for(owner, frames, time_batch, streams, submit, emit, frame_spec=No
     key = (shape, dtype, int(time_batch), int(streams), device)
     pipe = cache.get(key)
     if pipe is None:
+        # ONE cached pipeline per predictor: another frame format / time batch / stream count replaces it (an entry
+        # holds streams + 2 pinned host buffers and as many HBM buffers of a whole time batch -- 7.5 GB + 7.5 GB at
+        # configs[2], T = 32, 3 streams -- plus its thread pool; release_ingest_buffers() frees the last one)
+        for old in cache.values():
+            old.quiesce()
+            old.close()
+        cache.clear()
         pipe = cache[key] = FramePipeline(shape, dtype, time_batch, streams, submit, emit, device)
         return pipe
     return pipe.rebind(submit, emit)
@@ -252,4 +288,5 @@ def pipeline_for(owner, frames, time_batch, streams, submit, emit, frame_spec=No
 def release_ingest_buffers(owner):
     """Free the pinned staging / device buffers cached on a predictor by the drivers."""
     for pipe in owner.__dict__.pop("_ingest_cache", {}).values():
+        pipe.quiesce()
         pipe.close()

@@ -104,19 +104,24 @@ def predict2D_frames(predictor, frames, cfg, output_dir, params=None, time_batch
             return res, ev
 
         pipe, key = None, None
-        for frame in frames:
-            if not callable(frame):
-                frame = frame if torch.is_tensor(frame) and frame.is_cuda else _as_host(frame)
-                k = (frame.dtype, tuple(frame.shape), torch.is_tensor(frame))
-            else:
-                k = key if key is not None else ("fill",)
-            if pipe is None or k != key:
-                if pipe is not None:
-                    n += pipe.finish()
-                pipe, key = pipeline_for(predictor, frame, time_batch, 1, submit, emit, frame_spec), k
-            pipe.push(frame)
-        if pipe is not None:
-            n += pipe.finish()
+        try:
+            for frame in frames:
+                if not callable(frame):
+                    frame = frame if torch.is_tensor(frame) and frame.is_cuda else _as_host(frame)
+                    k = (frame.dtype, tuple(frame.shape), torch.is_tensor(frame))
+                else:
+                    k = key if key is not None else ("fill",)
+                if pipe is None or k != key:
+                    if pipe is not None:
+                        n += pipe.finish()
+                    pipe, key = pipeline_for(predictor, frame, time_batch, 1, submit, emit, frame_spec), k
+                pipe.push(frame)
+            if pipe is not None:
+                n += pipe.finish()
+        except BaseException:
+            from ._ingest import release_ingest_buffers
+            release_ingest_buffers(predictor)           # an aborted run leaves work in flight on the cached buffers
+            raise
     return n
 
 

@@ -84,8 +84,13 @@ def predict3D_frames(predictor, frame_sets, cameraMatrices, intrinsicMatrices,
     1e-5 mm from 8 on (the high-resolution BiFPN nodes then run in their row-streaming form,
     DESIGN.md section 1; a row does not depend on its position in the group or on `streams`).
     A short last group is padded with its last frame set and the padding rows are dropped.
-    streams > 1 keeps that many groups in flight on as many HIP streams;
-    rows still come out in frame order and are identical to the streams = 1 run."""
+    streams > 1 keeps that many groups in flight on as many HIP streams (host frame sets and frame sets already
+    resident in HBM alike); rows still come out in frame order and are identical to the streams = 1 run.
+
+    Retained memory: the predictor keeps ONE ingest pipeline (streams + 2 pinned host buffers and as many HBM
+    buffers of a whole time batch, e.g. 7.5 GB + 7.5 GB at 12 x 1280 x 1024 uint8, T = 32, 3 streams) for the next
+    call with the same frame format; a call with another format / time batch / stream count replaces it, an
+    aborted call drops it, `_ingest.release_ingest_buffers(predictor)` frees it."""
     from ._ingest import host_outputs, pipeline_for
     os.makedirs(output_dir, exist_ok=True)
     if params is not None:
@@ -126,19 +131,26 @@ def predict3D_frames(predictor, frame_sets, cameraMatrices, intrinsicMatrices,
             return res, ev
 
         pipe, key = None, None
-        for frames in frame_sets:
-            if not callable(frames):
-                frames = frames if torch.is_tensor(frames) and frames.is_cuda else _as_host(frames)
-                k = (frames.dtype, tuple(frames.shape), torch.is_tensor(frames))
-            else:
-                k = key if key is not None else ("fill",)
-            if pipe is None or k != key:                        # first frame set, or a new frame format
-                if pipe is not None:
-                    n += pipe.finish()
-                pipe, key = pipeline_for(predictor, frames, time_batch, streams, submit, emit, frame_spec), k
-            pipe.push(frames)
-        if pipe is not None:
-            n += pipe.finish()
+        try:
+            for frames in frame_sets:
+                if not callable(frames):
+                    frames = frames if torch.is_tensor(frames) and frames.is_cuda else _as_host(frames)
+                    k = (frames.dtype, tuple(frames.shape), torch.is_tensor(frames))
+                else:
+                    k = key if key is not None else ("fill",)
+                if pipe is None or k != key:                        # first frame set, or a new frame format
+                    if pipe is not None:
+                        n += pipe.finish()
+                    pipe, key = pipeline_for(predictor, frames, time_batch, streams, submit, emit, frame_spec), k
+                pipe.push(frames)
+            if pipe is not None:
+                n += pipe.finish()
+        except BaseException:
+            # an aborted run leaves copies / uploads / forwards in flight on the cached staging buffers: wait for
+            # them and drop the cache, so that a retry starts from fresh buffers
+            from ._ingest import release_ingest_buffers
+            release_ingest_buffers(predictor)
+            raise
     return n
 
 

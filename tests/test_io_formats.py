@@ -225,7 +225,20 @@ def test_predict3D_frames_pipeline_host_logic(tmp_path):
     assert P.predict3D_frames(pred, fills, None, None, None, cfg, out, time_batch=2,
                               frame_spec=((C, 4, 6, 3), torch.uint8)) == 3
     assert [r[0] for r in rows(out)] == ["4.0", "5.0", "6.0"] and Stub.calls == calls + 2
-    assert len(pred._ingest_cache) == 2                      # uint8 and fp32 staging, re-used by the fill run
+    # the predictor retains ONE staging pipeline (the last format's: uint8, re-used by the fill run); the fp32 one
+    # of the mixed run was closed when the format changed back
+    assert len(pred._ingest_cache) == 1 and next(iter(pred._ingest_cache))[1] == torch.uint8
+    # an aborted run (the frame iterator raises) drops the cache: nothing of it may touch the buffers a retry fills
+    def broken():
+        yield sets(1)[0]
+        raise RuntimeError("decoder died")
+    try:
+        P.predict3D_frames(pred, broken(), None, None, None, cfg, str(tmp_path / "broken"), time_batch=2)
+        raise AssertionError("the iterator's exception must propagate")
+    except RuntimeError as e:
+        assert "decoder died" in str(e)
+    assert not hasattr(pred, "_ingest_cache")
+    assert P.predict3D_frames(pred, iter(sets(3)), None, None, None, cfg, str(tmp_path / "retry"), time_batch=2) == 3
     release_ingest_buffers(pred)
     assert not hasattr(pred, "_ingest_cache")
 

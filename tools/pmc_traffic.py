@@ -39,6 +39,15 @@ SPECS = {
 }
 
 
+def workload_of(command):
+    """(--config, --model-size) of a bench command line (bench.py's defaults when absent)."""
+    words = command.split()
+
+    def opt(name, default):
+        return words[words.index(name) + 1] if name in words and words.index(name) + 1 < len(words) else default
+    return opt("--config", "cfg3"), opt("--model-size", "small")
+
+
 def csrc_sha256():
     """SHA-256 over the names and contents of every source file that goes into libjarvis_hip.so."""
     h = hashlib.sha256()
@@ -79,7 +88,10 @@ def main(fetch_db, write_db, time_batch, out, command):
                        "MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950). A bench name that covers "
                        "several device functions / shapes carries the dispatch-weighted average per launch. Written by "
                        "tools/pmc_traffic.py.",
-           "command": command, "time_batch": int(time_batch), "csrc_sha256": csrc_sha256()}
+           "command": command, "time_batch": int(time_batch), "csrc_sha256": csrc_sha256(),
+           # the workload the byte counts belong to: bench.py reports them only for this config and model size
+           # (several bench kernel names -- norm_apply, reproject_gather, deconv_k4s2T_c1 -- carry no shape)
+           "config": workload_of(command)[0], "model_size": workload_of(command)[1]}
     for bench_name, parts in SPECS.items():
         f, w = [], []
         for pattern, rule in parts:
