@@ -278,6 +278,11 @@ int jh_op_conv(int nd, int kind, int k, int stride, int pad, int cin, int cout,
 /* depthwise k x k stride 1: x (N,C,H,W), w_host (C,1,k,k) -> y. */
 int jh_op_depthwise(int k, int c, const float* w_host, const float* x_dev, int n, int h, int w,
                     int norm_act, float* y_dev, void* stream);
+/* ... with the squeeze-excite pooled sums of the same launch (MBConvBlock.forward,
+ * jarvis/efficienttrack/efficientnet.py:100-107: _depthwise_conv -> _gn1 -> swish -> adaptive_avg_pool2d): h, w <= 16;
+ * y_dev (N,C,h,w) RAW depthwise output, pool_dev (N,C) = sum over pixels of SiLU(InstanceNorm(y)). */
+int jh_op_depthwise_pool(int k, int c, const float* w_host, const float* x_dev, int n, int h, int w,
+                         float* y_dev, float* pool_dev, void* stream);
 
 /* One fused BiFPN node (jarvis/efficienttrack/model.py:301-353 fusion expressions + :223-232
  * SeparableConvBlock.forward, without its trailing InstanceNorm):

@@ -113,6 +113,8 @@ _SIGS = {
                    [c_void_p, c_int, c_void_p, c_void_p]),
     "jh_op_depthwise": (c_int, [c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                 c_void_p, c_void_p]),
+    "jh_op_depthwise_pool": (c_int, [c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                     c_void_p]),
     "jh_op_bifpn_node": (c_int, [c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_float), c_int, c_int, c_int,
                                  c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p]),

@@ -859,6 +859,43 @@ int jh_op_depthwise(int k, int c, const float* w_host, const float* x_dev, int n
   return 0;
 }
 
+// Depthwise + the squeeze-excite pooled sums of SiLU(InstanceNorm(y)) in one launch (the form MBConv blocks with
+// one-tile images use, efficientnet.py:100-107): y_dev (N,C,H,W) raw output, pool_dev (N,C) sums over the pixels.
+int jh_op_depthwise_pool(int k, int c, const float* w_host, const float* x_dev, int n, int h, int w,
+                         float* y_dev, float* pool_dev, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  JH_REQUIRE(depthwise_can_pool(h, w), "jh_op_depthwise_pool: the image must be one 16 x 16 tile");
+  Scratch sc;
+  Act x, y;
+  if (sc.act(n, 1, h, w, c, &x)) return 1;
+  if (sc.act(n, 1, h, w, c, &y)) return 1;
+  std::vector<float> wt((size_t)k * k * x.Cp, 0.f);
+  for (int ch = 0; ch < c; ++ch)
+    for (int t = 0; t < k * k; ++t) wt[(size_t)t * x.Cp + ch] = w_host[(size_t)ch * k * k + t];
+  float* wd; double *stats = nullptr, *pool = nullptr;
+  if (sc.get(reinterpret_cast<void**>(&wd), wt.size() * sizeof(float))) return 1;
+  JH_CHECK_HIP(hipMemcpyAsync(wd, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice, s));
+  const size_t nst = (size_t)n * x.Cp * kStatW, npl = (size_t)n * x.Cp * kLimbs;
+  if (sc.get(reinterpret_cast<void**>(&stats), nst * sizeof(double))) return 1;
+  if (sc.get(reinterpret_cast<void**>(&pool), npl * sizeof(double))) return 1;
+  JH_CHECK_HIP(hipMemsetAsync(stats, 0, nst * sizeof(double), s));
+  JH_CHECK_HIP(hipMemsetAsync(pool, 0, npl * sizeof(double), s));
+  if (launch_to_channel_last(x_dev, x, s)) return 1;
+  if (launch_depthwise(x, wd, k, y.p, stats, s, pool)) return 1;
+  if (launch_from_channel_last(y, y_dev, s)) return 1;
+  std::vector<double> hp(npl);
+  JH_CHECK_HIP(hipMemcpyAsync(hp.data(), pool, npl * sizeof(double), hipMemcpyDeviceToHost, s));
+  JH_CHECK_HIP(hipStreamSynchronize(s));
+  std::vector<float> out((size_t)n * c);
+  for (int i = 0; i < n; ++i)
+    for (int ch = 0; ch < c; ++ch) {
+      const double* q = hp.data() + ((size_t)i * x.Cp + ch) * kLimbs;
+      out[(size_t)i * c + ch] = (float)((q[0] + q[1]) + q[2]);
+    }
+  JH_CHECK_HIP(hipMemcpy(pool_dev, out.data(), out.size() * sizeof(float), hipMemcpyHostToDevice));
+  return 0;
+}
+
 
 // One fused BiFPN node (csrc/bifpn_node.hip) as a unit-test entry point: every input is a RAW
 // tensor that the node normalises on load with its own InstanceNorm statistics (computed here

@@ -52,14 +52,17 @@ __device__ __forceinline__ void block_channel_reduce(float4 s1, float4 s2, int n
 // SiLU through v_exp_f32 / v_rcp_f32, as the convolutions apply it when they stage the same tensor.
 // R1N: the residual operand r1 is itself a raw tensor whose InstanceNorm + ReLU (statistics `stats1`) is
 // applied here, on load -- the V2V stage-entry tensors are then never materialised in normalised form.
+// Block size 256, 512 or 1024 (launcher: whichever leaves the fewest lanes without a channel quad -- a 528-channel
+// tensor has 132 quads: one pixel row per 256 threads used 132 of them).
 template <int ACT, bool R1, bool R2, bool Y, bool R1N = false>
-__global__ __launch_bounds__(256) void norm_apply_kernel(
+__global__ __launch_bounds__(1024) void norm_apply_kernel(
     const float* __restrict__ x, const double* __restrict__ stats, float eps,
     const float* __restrict__ r1, const float* __restrict__ r2, float* __restrict__ y,
     double* __restrict__ pool, int P, int Cp, int ppb, const double* __restrict__ stats1 = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int q = Cp >> 2;
-  const int rows = 256 / q;
+  const int BT = blockDim.x;
+  const int rows = BT / q;
   const int tid = threadIdx.x;
   const bool active = tid < rows * q;
   const int c4 = tid % q, row = tid / q;
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(
   float4 mean = make_float4(0, 0, 0, 0), rstd = make_float4(1, 1, 1, 1);
   if (stats) {
     float* mr = sm + (pool ? rows * q * 4 : 0);          // [Cp] mean, [Cp] rstd
-    for (int c = tid; c < Cp; c += 256) {
+    for (int c = tid; c < Cp; c += BT) {
       const double* st = stats + ((size_t)n * Cp + c) * kStatW;
       const double mu = exact_read(st) / (double)P;
       double var = exact_read(st + kLimbs) / (double)P - mu * mu;
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(
   float4 mean1 = make_float4(0, 0, 0, 0), rstd1 = make_float4(1, 1, 1, 1);
   if (R1N) {
     float* mr = sm + (pool ? rows * q * 4 : 0);
-    for (int c = tid; c < Cp; c += 256) {
+    for (int c = tid; c < Cp; c += BT) {
       const double* st = stats1 + ((size_t)n * Cp + c) * kStatW;
       const double mu = exact_read(st) / (double)P;
       double var = exact_read(st + kLimbs) / (double)P - mu * mu;
@@ -157,7 +160,11 @@ int launch_norm_apply(const Act& x, const double* stats, float eps, int act, con
   const int P = (int)x.pixels();
   const int q = x.Cp / 4;
   JH_REQUIRE(q >= 1 && q <= 256, "channel count out of range for norm_apply");
-  const int rows = 256 / q;
+  // threads per block: a function of the channel count alone (part of the pooled sums' arithmetic, see below)
+  int bt = 256;
+  for (int cand = 512; cand <= 1024; cand *= 2)
+    if ((cand / q) * q * bt > (bt / q) * q * cand + cand * bt / 16) bt = cand;      // > 1/16 better lane use
+  const int rows = bt / q;
   // 8..64 pixels per row-slot, at most 64 blocks per image.  Chosen from the image size alone:
   // the pooled sums are sums of per-block fp32 partials, so the blocking is part of the
   // arithmetic and must not depend on the batch size.
@@ -169,17 +176,17 @@ int launch_norm_apply(const Act& x, const double* stats, float eps, int act, con
   if (r1_stats) {     // residual operand normalised (+ReLU) on load: V2V residual blocks only
     JH_REQUIRE(stats && r1 && y && act == ACT_RELU && !pool, "norm_apply: normalised residual operand");
     if (r2)
-      hipLaunchKernelGGL((norm_apply_kernel<ACT_RELU, true, true, true, true>), grid, dim3(256), sm, s, x.p, stats, eps,
+      hipLaunchKernelGGL((norm_apply_kernel<ACT_RELU, true, true, true, true>), grid, dim3(bt), sm, s, x.p, stats, eps,
                          r1, r2, y, pool, P, x.Cp, ppb, r1_stats);
     else
-      hipLaunchKernelGGL((norm_apply_kernel<ACT_RELU, true, false, true, true>), grid, dim3(256), sm, s, x.p, stats, eps,
+      hipLaunchKernelGGL((norm_apply_kernel<ACT_RELU, true, false, true, true>), grid, dim3(bt), sm, s, x.p, stats, eps,
                          r1, r2, y, pool, P, x.Cp, ppb, r1_stats);
     JH_CHECK_HIP(hipGetLastError());
     return 0;
   }
 #define JH_NA(A, B1, B2, BY)                                                                              \
   if (act == A && (r1 != nullptr) == B1 && (r2 != nullptr) == B2 && (y != nullptr) == BY) {             \
-    hipLaunchKernelGGL((norm_apply_kernel<A, B1, B2, BY>), grid, dim3(256), sm, s, x.p, stats, eps, r1, r2, y, \
+    hipLaunchKernelGGL((norm_apply_kernel<A, B1, B2, BY>), grid, dim3(bt), sm, s, x.p, stats, eps, r1, r2, y, \
                        pool, P, x.Cp, ppb, nullptr);                                                               \
     JH_CHECK_HIP(hipGetLastError());                                                                      \
     return 0;                                                                                             \
@@ -237,10 +244,15 @@ int launch_se_gate(const double* pool, int N, int C, int Cp, int S, float inv_hw
 // registers and produces 1 x 4 output strips, so each staged value is read from LDS
 // (k+3)/4k times per tap instead of once.  Optional InstanceNorm statistics of the
 // output are reduced in the block and added with fp64 atomics.
-template <int K, int CC>
+// POOL (images of one tile, i.e. H, W <= 16, channel chunk 16): the workgroup holds every output of its 16 channels
+// of the image, so it also finishes InstanceNorm + SiLU for squeeze-excite in the same launch -- mean / rstd from its
+// own (complete) statistics with norm_apply's expressions, then sum_p SiLU((y - mean) rstd) per channel from the
+// outputs still in registers -> `pool`.  The second pass over the 6 x expanded tensor (norm_apply in pooled-sums-only
+// form, efficientnet.py:102-106) is not launched for these blocks.
+template <int K, int CC, bool POOL = false>
 __global__ __launch_bounds__(256) void depthwise_lds_kernel(
     const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
-    double* __restrict__ stats, int H, int W, int Cp) {
+    double* __restrict__ stats, int H, int W, int Cp, double* __restrict__ pool = nullptr) {
   constexpr int T = 16, HT = T + K - 1, SP = CC + 4;
   constexpr int QN = CC / 4, SL = 256 / QN;         // channel quads of a chunk, pixel slots (threads per quad)
   constexpr int QS = QN == 8 ? 3 : 2;               // log2(QN)
@@ -287,12 +299,14 @@ __global__ __launch_bounds__(256) void depthwise_lds_kernel(
   const bool active = c4 < q;
   __syncthreads();
   df2 s1l = (df2){0.f, 0.f}, s1h = s1l, s2l = s1l, s2h = s1l;
+  static_assert(!POOL || SL == 64, "the fused pooled sums keep a thread's one strip in registers");
+  df2 al[4], ah[4];                                // packed fp32 FMAs: two channels per instruction
+  unsigned okm = 0;                                // (POOL) which of the strip's four pixels are inside the image
   if (active) {
 #pragma unroll 1
     for (int j = 0; j < 64 / SL; ++j) {
       const int g = (tid >> QS) + SL * j;          // 64 strips: 16 rows x 4 strips of 4 pixels
       const int ty = g >> 2, tx0 = (g & 3) * 4;
-      df2 al[4], ah[4];                            // packed fp32 FMAs: two channels per instruction
 #pragma unroll
       for (int o = 0; o < 4; ++o) { al[o] = (df2){0.f, 0.f}; ah[o] = al[o]; }
 #pragma unroll 1
@@ -322,6 +336,7 @@ __global__ __launch_bounds__(256) void depthwise_lds_kernel(
               (df4){al[o][0], al[o][1], ah[o][0], ah[o][1]};
           s1l += al[o]; s1h += ah[o];
           s2l += al[o] * al[o]; s2h += ah[o] * ah[o];
+          okm |= 1u << o;
         }
       }
     }
@@ -343,20 +358,83 @@ __global__ __launch_bounds__(256) void depthwise_lds_kernel(
       red2[val * 8 + part] = acc;
     }
     __syncthreads();
+    float* tot = red2 + QN * 8 * 8;                // (POOL) [QN * 8] totals of the image, then [CC] mean, [CC] rstd
     for (int i = tid; i < q * 8; i += 256) {
       const int comp = i & 3, sq = (i >> 2) & 1, cq = i >> 3;
       float acc = 0.f;
 #pragma unroll
       for (int r = 0; r < 8; ++r) acc += red2[i * 8 + r];
       exact_add(stats + (((size_t)n * Cp + c0 + cq * 4 + comp) * 2 + sq) * kLimbs, (double)acc);
+      if (POOL) tot[i] = acc;
+    }
+    if (POOL) {
+      // the image is one tile: `tot` ARE its statistics (the only contribution to stats[n][c]); mean / rstd exactly
+      // as norm_apply_kernel derives them from the accumulators
+      float* mr = tot + QN * 8;
+      __syncthreads();
+      if (tid < q * 4) {
+        const int cq = tid >> 2, comp = tid & 3;
+        const double P = (double)(H * W);
+        const double mu = (double)tot[(cq * 2 + 0) * 4 + comp] / P;
+        double var = (double)tot[(cq * 2 + 1) * 4 + comp] / P - mu * mu;
+        if (var < 0.0) var = 0.0;
+        mr[tid] = (float)mu;
+        mr[CC + tid] = (float)(1.0 / sqrt(var + 1e-5));
+      }
+      __syncthreads();
+      df4 ps = (df4){0.f, 0.f, 0.f, 0.f};
+      if (active) {
+        const df4 mean = *reinterpret_cast<const df4*>(mr + c4 * 4);
+        const df4 rstd = *reinterpret_cast<const df4*>(mr + CC + c4 * 4);
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+          if (okm >> o & 1) {
+            ps[0] += silu_fast((al[o][0] - mean[0]) * rstd[0]);
+            ps[1] += silu_fast((al[o][1] - mean[1]) * rstd[1]);
+            ps[2] += silu_fast((ah[o][0] - mean[2]) * rstd[2]);
+            ps[3] += silu_fast((ah[o][1] - mean[3]) * rstd[3]);
+          }
+      }
+      __syncthreads();                             // (mr has been read; the reduce below reuses the front of sm)
+      reinterpret_cast<df4*>(sm)[(size_t)(tid >> QS) * QN + c4] = ps;        // [SL rows][QN quads][4]
+      __syncthreads();
+      for (int i = tid; i < q * 4 * 8; i += 256) {
+        const int part = i & 7, val = i >> 3;      // val = (quad, component)
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < SL / 8; ++r) acc += sm[((size_t)(part * (SL / 8) + r) * QN + (val >> 2)) * 4 + (val & 3)];
+        red2[val * 8 + part] = acc;
+      }
+      __syncthreads();
+      for (int i = tid; i < q * 4; i += 256) {
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc += red2[i * 8 + r];
+        exact_add(pool + ((size_t)n * Cp + c0 + i) * kLimbs, (double)acc);
+      }
     }
   }
 }
 
-int launch_depthwise(const Act& x, const float* w, int k, float* y, double* stats, hipStream_t s) {
+bool depthwise_can_pool(int H, int W) { return H <= 16 && W <= 16; }
+
+int launch_depthwise(const Act& x, const float* w, int k, float* y, double* stats, hipStream_t s, double* pool) {
   JH_REQUIRE(x.D == 1, "depthwise is 2D only");
   JH_REQUIRE(k == 3 || k == 5, "depthwise kernel size must be 3 or 5");
   const int tiles = ((x.H + 15) / 16) * ((x.W + 15) / 16);
+  if (pool) {
+    // fused squeeze-excite pooled sums: one tile per image, channel chunk 16 (the form does not depend on the batch)
+    JH_REQUIRE(depthwise_can_pool(x.H, x.W) && stats, "fused depthwise pooled sums need a one-tile image and statistics");
+    dim3 grid(1, (x.Cp + 15) / 16, x.N);
+    const int ht = 16 + k - 1;
+    size_t lds = (size_t)(ht * ht * (16 + 4) + k * k * 16) * sizeof(float);
+    const size_t red = (size_t)(64 * 4 * 8 + 4 * 8 * 8 + 4 * 8 + 2 * 16) * sizeof(float);
+    if (lds < red) lds = red;
+    if (k == 3) hipLaunchKernelGGL((depthwise_lds_kernel<3, 16, true>), grid, dim3(256), lds, s, x.p, w, y, stats, x.H, x.W, x.Cp, pool);
+    else hipLaunchKernelGGL((depthwise_lds_kernel<5, 16, true>), grid, dim3(256), lds, s, x.p, w, y, stats, x.H, x.W, x.Cp, pool);
+    JH_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   // Channel chunk per workgroup: 16 (33.6 KB of LDS at k = 5: four workgroups per CU) unless JH_DW_CC=32 (60.8 KB,
   // two per CU: the round-2 form).  The kernel is latency-bound; the chunk is part of no sum (statistics are
   // per channel), so the choice does not depend on anything but the knob.

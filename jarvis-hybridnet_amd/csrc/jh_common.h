@@ -193,8 +193,10 @@ int launch_se_gate(const double* pool, int N, int C, int Cp, int S, float inv_hw
                    const float* wr, const float* br, const float* we, const float* be,
                    float* gate, hipStream_t s);
 // depthwise k x k stride-1 conv, weights [k*k][Cp]; optional IN statistics.
+// pool != nullptr: squeeze-excite pooled sums of SiLU(InstanceNorm(y)) in the same launch (one-tile images only)
+bool depthwise_can_pool(int H, int W);
 int launch_depthwise(const Act& x, const float* w, int k, float* y, double* stats,
-                     hipStream_t s);
+                     hipStream_t s, double* pool = nullptr);
 // weighted fusion node of the BiFPN: y = act(sum_i w[i] * resample_i(in_i))
 enum FuseMode { FUSE_SAME = 0, FUSE_UP2 = 1, FUSE_UP4 = 2, FUSE_POOL2 = 3 };
 struct FuseArgs {

@@ -174,7 +174,8 @@ int Plan::add_conv(const ParamMap& pm, const ConvDesc& d, const std::string& wke
 void Plan::add_norm(const Act& x, size_t stats_off, int act, const float* r1, const float* r2,
                     float* y, long pool_off, long r1_stats_off) {
   const double el = (double)x.N * x.pixels() * x.C;
-  push("norm_apply", 8.0 * el, 4.0 * el * (2 + (r1 ? 1 : 0) + (r2 ? 1 : 0)),
+  // (bytes: one read of x and of each residual operand, one write of y -- none for the pooled-sums-only form)
+  push("norm_apply", 8.0 * el, 4.0 * el * (1 + (y ? 1 : 0) + (r1 ? 1 : 0) + (r2 ? 1 : 0)),
        [this, x, stats_off, act, r1, r2, y, pool_off, r1_stats_off](hipStream_t s) {
     return launch_norm_apply(x, sc(stats_off), 1e-5f, act, r1, r2, y,
                              pool_off >= 0 ? sc((size_t)pool_off) : nullptr, s,
@@ -254,6 +255,11 @@ int EffTrackPlan::mbconv(const ParamMap& pm, const std::string& p, int stage, in
   Act raw;
   if (new_act(x.N, 1, Ho, Wo, mid, &raw)) return 1;
   size_t st1 = 0;
+  // squeeze-excite pooled sums: [N][Cp][kLimbs].  Depthwise blocks whose image is one 16 x 16 tile get them from
+  // the depthwise launch itself (the workgroup owns the whole image of its channels); everything else from a
+  // pooled-sums-only pass over the raw tensor.
+  const size_t pool = scratch((size_t)raw.N * raw.Cp * kLimbs);
+  bool pooled = false;
   if (stage < 4) {
     // "fused" path: one dense k x k conv; _expand_conv is never executed
     if (add_conv(pm, conv_desc(2, k, stride, k / 2, cin, mid), p + "_depthwise_conv.weight", "",
@@ -274,16 +280,16 @@ int EffTrackPlan::mbconv(const ParamMap& pm, const std::string& p, int stage, in
     float* wd = nullptr;
     if (upload(wt, &wd)) return 1;
     st1 = scratch((size_t)raw.N * raw.Cp * kStatW);
-    push("depthwise_k" + std::to_string(k), 2.0 * raw.N * raw.pixels() * mid * k * k,
-         8.0 * raw.N * raw.pixels() * mid, [this, e, wd, k, raw, st1](hipStream_t s) {
-      return launch_depthwise(e, wd, k, raw.p, sc(st1), s);
+    pooled = depthwise_can_pool(Ho, Wo) && JH_ENV_KNOB("JH_DW_POOL") != 0;
+    push(std::string("depthwise_k") + std::to_string(k) + (pooled ? "pool" : ""), 2.0 * raw.N * raw.pixels() * mid * k * k,
+         8.0 * raw.N * raw.pixels() * mid, [this, e, wd, k, raw, st1, pool, pooled](hipStream_t s) {
+      return launch_depthwise(e, wd, k, raw.p, sc(st1), s, pooled ? sc(pool) : nullptr);
     });
   }
   // _gn1 + swish: only its per-(n,c) pooled sums (squeeze-excite) are computed here; the
   // normalised tensor itself is never written -- the project conv re-applies
   // InstanceNorm + SiLU (+ the SE gate) while it stages its operand
-  const size_t pool = scratch((size_t)raw.N * raw.Cp * kLimbs);
-  add_norm(raw, st1, ACT_SILU, nullptr, nullptr, nullptr, (long)pool);
+  if (!pooled) add_norm(raw, st1, ACT_SILU, nullptr, nullptr, nullptr, (long)pool);
   // squeeze-excite gate
   const float *wr, *br, *we, *be;
   if (get(pm, p + "_se_reduce.weight", (size_t)squeeze * mid, &wr)) return 1;

@@ -166,6 +166,26 @@ def test_depthwise(k, c, H, W, norm_act):
     assert e < 2e-5 * (10 if norm_act >= 0 else 1)
 
 
+@pytest.mark.parametrize("k,c,H,W", [(5, 240, 16, 16), (5, 672, 16, 16), (3, 88, 8, 8), (5, 336, 12, 14), (5, 528, 16, 16)])
+def test_depthwise_fused_se_pool(k, c, H, W):
+    """One-tile images: the depthwise launch also delivers sum_p SiLU(InstanceNorm(y)) per (image, channel) -- the
+    squeeze-excite pooling of MBConvBlock.forward (efficientnet.py:100-107) without a second pass over y."""
+    from jarvis_hybridnet_amd import _native as N
+    g = torch.Generator().manual_seed(k + c + H)
+    x = torch.randn(3, c, H, W, generator=g)
+    w = torch.randn(c, 1, k, k, generator=g) / k
+    ref = F.conv2d(x, w, None, 1, k // 2, 1, c)
+    ref_pool = F.silu(F.instance_norm(ref, eps=1e-5)).sum((2, 3))
+    xc, y = cuda(x), torch.empty(ref.shape, device="cuda")
+    pool = torch.empty((3, c), device="cuda")
+    N.check(N.lib().jh_op_depthwise_pool(k, c, w.contiguous().data_ptr(), xc.data_ptr(), 3, H, W, y.data_ptr(),
+                                         pool.data_ptr(), N.stream()))
+    torch.cuda.synchronize()
+    e, ep = rel_err(y, ref), rel_err(pool, ref_pool)
+    report("depthwise_pool", k=k, c=c, rel=e, pool_rel=ep)
+    assert e < 2e-5 and ep < 1e-4
+
+
 @pytest.mark.parametrize("cin,cout,N,G,in_norm", [(46, 46, 5, 32, 1), (92, 92, 20, 16, 0), (60, 60, 3, 48, 1)])
 def test_conv3d_winograd_persistent(cin, cout, N, G, in_norm, monkeypatch):
     """The persistent wave-specialised Winograd kernel (csrc/conv3d_wino_pw.hip, the default for
