@@ -360,6 +360,8 @@ void bifpn_rows_kernel(const NodeArgs a, int seg_rows, int strips) {
 // (JH_NODE_ROWS=0: never; JH_NODE_ROWS88=0: not at 88 channels).
 bool bifpn_rows_wg_shape_ok(const NodeArgs& a);                 // csrc/bifpn_rows_wg.hip
 int launch_bifpn_rows_wg(const NodeArgs& a, hipStream_t s);
+bool bifpn_rows_ps_ok(const NodeArgs& a, int seg_rows, int strips, int segs);      // csrc/bifpn_rows_ps.hip
+int launch_bifpn_rows_ps(const NodeArgs& a, int seg_rows, int strips, int segs, hipStream_t s);
 
 bool bifpn_rows_eligible(const NodeArgs& a) {
   if (JH_ENV_KNOB("JH_NODE_ROWS") == 0 || a.rows == 0) return false;
@@ -405,6 +407,9 @@ static int launch_rows_rc(const NodeArgs& a, hipStream_t s) {
   seg_rows = (seg_rows + 1) & ~1;                // (even: the kernel's row loop is unrolled by two on row parity)
   if (seg_rows > a.H) seg_rows = a.H;
   const int segs = (a.H + seg_rows - 1) / seg_rows;
+  // 88 channels at bench scale: producer / consumer wave pairs (csrc/bifpn_rows_ps.hip) -- the same arithmetic per
+  // output value and the same segmentation, so the results are bit-equal to the kernel below
+  if (RC == 88 && bifpn_rows_ps_ok(a, seg_rows, strips, segs)) return launch_bifpn_rows_ps(a, seg_rows, strips, segs, s);
   const size_t lds = RowGeo<RC>::lds_bytes();
   const dim3 grid(strips * segs, a.N);
 #define JH_ROWS(NIN, M1, M2, ACT, POOL) \

@@ -56,5 +56,6 @@ for i, name, ms, fam, frac, fl, by in rows:
     lines.append("%d\t%s\t%.4f\t%s\t%.3f\t%.3f\t%.2f\t%.1f" % (i, name, ms, fam, frac, cum, fl / 1e9, by / 1e6))
 text = "\n".join(lines)
 if a.out:
+    os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
     open(a.out, "w").write(text + "\n")
 print(text)
