@@ -18,7 +18,10 @@
 // partial sums cross waves through LDS (A^T along y mixes fy, i.e. waves), wave w finishes
 // z-slice w and hands its four (oy, ox) output phases to the shared epilogue (bias, 16-byte
 // stores, fused InstanceNorm statistics).
+#include <array>
 #include <cstdlib>
+#include <map>
+#include <mutex>
 #include <vector>
 #include "conv_mfma.h"
 #include "conv3d_wino.h"
@@ -31,10 +34,12 @@ constexpr int kWSV = 12;                                    // V row stride (flo
 // kWTZ = z-slices per workgroup: 4 (48 accumulator tiles per wave, one workgroup per CU) or
 // 2 (24 tiles, <= 256 registers and 62 KB of LDS: two workgroups per CU, so one's patch
 // staging, input transform and epilogue run under the other's MFMAs).
-template <int NR, int kWTZ>
+// SH: the launch tiles its z-slices with the block shapes of conv3d_wino.h (an extent with a remainder of 1..4 voxels);
+// !SH is the plain grid of 8 x 8-voxel blocks, and every shape expression below folds to that constant.
+template <int NR, int kWTZ, bool SH = false>
 __global__ __launch_bounds__(256, (kWTZ == 2 ? 2 : 1)) void conv3d_wino_kernel(const WinoArgs a) {
   constexpr int kWPZ = kWTZ + 2;
-  constexpr int kWNP = kWPZ * kWPY * kWPX;                  // 600 / 400 patch pixels
+  constexpr int kWNP = kWPZ * (SH ? 108 : kWPY * kWPX);     // 600 / 400 patch pixels (648 / 432 with 18 x 6 patches)
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
   const int nrm_floats = a.in_stats ? 2 * a.cin_p : 0;
   float* nrm = lds_all;
@@ -47,11 +52,20 @@ __global__ __launch_bounds__(256, (kWTZ == 2 ? 2 : 1)) void conv3d_wino_kernel(c
   const int mrow = lane & 15, kq = lane >> 4;
 
   const BlockId bid = xcd_block();
-  const int bx_n = (a.W + kWTX - 1) / kWTX, by_n = (a.H + kWTY - 1) / kWTY;
-  int t = bid.x;
-  const int x0 = (t % bx_n) * kWTX; t /= bx_n;
-  const int y0 = (t % by_n) * kWTY; t /= by_n;
-  const int z0 = t * kWTZ;
+  int x0, y0, z0, lc = 2, hlim = a.H, wlim = a.W;
+  if (SH) {
+    const WinoTile wt = wino_decode(a.tiling, 1, a.H, a.W, kWTZ, (int)bid.x);
+    x0 = wt.x0; y0 = wt.y0; z0 = wt.z0; lc = wt.lc; hlim = wt.hlim; wlim = wt.wlim;
+  } else {
+    const int bx_n = (a.W + kWTX - 1) / kWTX, by_n = (a.H + kWTY - 1) / kWTY;
+    int t = bid.x;
+    x0 = (t % bx_n) * kWTX; t /= bx_n;
+    y0 = (t % by_n) * kWTY; t /= by_n;
+    z0 = t * kWTZ;
+  }
+  // patch of this block: (2 rows + 2) x (2 cols + 2) pixels per z-slice; tile -> (row, column) of the block
+  const int PW = SH ? (2 << lc) + 2 : kWPX, PH = SH ? (32 >> lc) + 2 : kWPY;
+  const int cmask = (1 << lc) - 1;
   const int nb0 = bid.y * NR;
   const int n = bid.z;
   const int nk8 = a.cin_p >> 3, nb = a.cout_p16 >> 4;
@@ -90,9 +104,9 @@ __global__ __launch_bounds__(256, (kWTZ == 2 ? 2 : 1)) void conv3d_wino_kernel(c
   for (int it = 0; it < ITER; ++it) {
     const int idx = tid + it * 256;
     const int q = idx & 1, pix = idx >> 1;
-    const int px = pix % kWPX, py = (pix / kWPX) % kWPY, pz = pix / (kWPX * kWPY);
+    const int px = pix % PW, py = (pix / PW) % PH, pz = pix / (PW * PH);
     const int iz = z0 - 1 + pz, iy = y0 - 1 + py, ix = x0 - 1 + px;
-    const bool ok = idx < kWNP * 2 && iz >= 0 && iz < a.D && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    const bool ok = idx < kWPZ * PW * PH * 2 && iz >= 0 && iz < a.D && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
     poff[it] = ok ? ((iz * a.H + iy) * a.W + ix) * a.cin_p + q * 4 : 0;     // < 2^31 elements per image
     okmask |= ok ? (1u << it) : 0u;
   }
@@ -149,15 +163,15 @@ __global__ __launch_bounds__(256, (kWTZ == 2 ? 2 : 1)) void conv3d_wino_kernel(c
     // 2. input transform: thread -> (z-slice pz, tile, channel quad q); 6 x 16 x 2 = 192 items
     if (tid < kWPZ * 32) {
       const int q = tid & 1, tile = (tid >> 1) & 15, pz = tid >> 5;
-      const int ty = tile >> 2, tx = tile & 3;
-      const float* rb = R + ((pz * kWPY + 2 * ty) * kWPX + 2 * tx) * 8 + q * 4;
+      const int ty = tile >> lc, tx = tile & cmask;
+      const float* rb = R + ((pz * PH + 2 * ty) * PW + 2 * tx) * 8 + q * 4;
       float4 tr[4][4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float4 d0 = *reinterpret_cast<const float4*>(rb + (r * kWPX + 0) * 8);
-        const float4 d1 = *reinterpret_cast<const float4*>(rb + (r * kWPX + 1) * 8);
-        const float4 d2 = *reinterpret_cast<const float4*>(rb + (r * kWPX + 2) * 8);
-        const float4 d3 = *reinterpret_cast<const float4*>(rb + (r * kWPX + 3) * 8);
+        const float4 d0 = *reinterpret_cast<const float4*>(rb + (r * PW + 0) * 8);
+        const float4 d1 = *reinterpret_cast<const float4*>(rb + (r * PW + 1) * 8);
+        const float4 d2 = *reinterpret_cast<const float4*>(rb + (r * PW + 2) * 8);
+        const float4 d3 = *reinterpret_cast<const float4*>(rb + (r * PW + 3) * 8);
         tr[r][0] = make_float4(d0.x - d2.x, d0.y - d2.y, d0.z - d2.z, d0.w - d2.w);
         tr[r][1] = make_float4(d1.x + d2.x, d1.y + d2.y, d1.z + d2.z, d1.w + d2.w);
         tr[r][2] = make_float4(d2.x - d1.x, d2.y - d1.y, d2.z - d1.z, d2.w - d1.w);
@@ -257,11 +271,12 @@ __global__ __launch_bounds__(256, (kWTZ == 2 ? 2 : 1)) void conv3d_wino_kernel(c
           v[0] = p[1].x - p[2].x - p[3].x; v[1] = p[1].y - p[2].y - p[3].y;
           v[2] = p[1].z - p[2].z - p[3].z; v[3] = p[1].w - p[2].w - p[3].w;
         }
-        const int yy = y0 + 2 * kq + oy;
+        // a lane holds tiles 4 kq + r (r = 0..3) of the block: tile -> (row tile >> lc, column tile & cmask)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           v[r] += bvl;
-          if (ch_ok && oz < a.D && yy < a.H && x0 + 2 * r + ox < a.W) {
+          const int tl = 4 * kq + r;
+          if (ch_ok && oz < a.D && y0 + 2 * (tl >> lc) + oy < hlim && x0 + 2 * (tl & cmask) + ox < wlim) {
             s1[nr] += v[r];
             s2[nr] += v[r] * v[r];
           }
@@ -273,9 +288,10 @@ __global__ __launch_bounds__(256, (kWTZ == 2 ? 2 : 1)) void conv3d_wino_kernel(c
           x = (jq & 2) ? v[0] : v[2]; y = quad_xor2(x); if (jq & 2) v[0] = y; else v[2] = y;
           x = (jq & 2) ? v[1] : v[3]; y = quad_xor2(x); if (jq & 2) v[1] = y; else v[3] = y;
         }
-        const int xx = x0 + 2 * jq + ox;
+        const int tj = 4 * kq + jq;                         // (after the transpose: tile 4 kq + jq)
+        const int yy = y0 + 2 * (tj >> lc) + oy, xx = x0 + 2 * (tj & cmask) + ox;
         const int c0 = (nb0 + nr) * 16 + (mrow & ~3);
-        if (c0 < a.cout_p && oz < a.D && yy < a.H && xx < a.W)
+        if (c0 < a.cout_p && oz < a.D && yy < hlim && xx < wlim)
           *reinterpret_cast<float4*>(yb + ((size_t)(oz * a.H + yy) * a.W + xx) * a.cout_p + c0) =
               make_float4(v[0], v[1], v[2], v[3]);
       }
@@ -309,9 +325,9 @@ __global__ __launch_bounds__(256, (kWTZ == 2 ? 2 : 1)) void conv3d_wino_kernel(c
   }
 }
 
-template <int NR, int TZ>
+template <int NR, int TZ, bool SH = false>
 static int launch_wino_nr(const WinoArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-  auto kern = conv3d_wino_kernel<NR, TZ>;
+  auto kern = conv3d_wino_kernel<NR, TZ, SH>;
   static bool big = false;
   if (!big) {
     JH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -375,8 +391,44 @@ int wino_variant_from_env() {
   return 4;
 }
 
+// Host side of the persistent kernel's tables (conv3d_wino.h): the loader's per-shape patch tables, then the tiles of
+// one column-block group in the kernel's linear order.  Empty for volumes without remainder strips.
+std::vector<int> wino_tables(int N, int D, int H, int W, int cin_p) {
+  const WinoTiling g = wino_tiling(D, H, W, 4);
+  std::vector<int> t;
+  if (!g.shaped) return t;
+  t.assign((size_t)3 * kWinoShapeWords, 0);
+  const int rz = D % 4 ? D % 4 : 4;
+  for (int lc = 1; lc <= 3; ++lc) {
+    const int PW = (2 << lc) + 2, PH = (32 >> lc) + 2, TH = 32 >> lc, TW = 2 << lc;
+    const int hy = H - (lc == 3 ? g.H44 : 0), wx = W - (lc == 1 ? g.W44 : 0);
+    const int ry = hy % TH ? hy % TH : TH, rx = wx % TW ? wx % TW : TW;
+    int* tab = t.data() + (size_t)(lc - 1) * kWinoShapeWords;
+    for (int lane = 0; lane < 64; ++lane) {
+      unsigned m[7] = {0, 0, 0, 0, 0, 0, 0};
+      for (int it = 0; it < kWinoShapeIter; ++it) {
+        const int idx = lane + it * 64, pix = idx >> 1, q = lane & 1;
+        const int px = pix % PW, py = (pix / PW) % PH, pz = pix / (PW * PH);
+        tab[it * 64 + lane] = (((pz * H + py) * W + px) * cin_p + q * 4) * 4;
+        m[0] |= (unsigned)(pz == 0) << it; m[1] |= (unsigned)(pz > rz) << it;
+        m[2] |= (unsigned)(py == 0) << it; m[3] |= (unsigned)(py > ry) << it;
+        m[4] |= (unsigned)(px == 0) << it; m[5] |= (unsigned)(px > rx) << it;
+        m[6] |= (unsigned)(idx >= 6 * PW * PH * 2) << it;
+      }
+      for (int k = 0; k < 7; ++k) tab[(kWinoShapeIter + k) * 64 + lane] = (int)m[k];
+    }
+  }
+  const int n = N * g.slabs * wino_blocks_per_slab(g);
+  for (int r = 0; r < n; ++r) {
+    const WinoTileEntry e = wino_pack_tile(wino_decode(g, N, H, W, 4, r));
+    t.push_back(e.x);
+    t.push_back(e.y);
+  }
+  return t;
+}
+
 int launch_conv3d_wino(const ConvWeights& w, const Act& x, const Act& y, double* stats, hipStream_t s,
-                       const InNorm* in, int variant) {
+                       const InNorm* in, int variant, const int* tables) {
   JH_REQUIRE(x.Cp == w.cin_p && x.N == y.N && x.D == y.D && x.H == y.H && x.W == y.W, "wino shapes");
   WinoArgs a{};
   a.x = x.p; a.y = y.p; a.u = w.w; a.bias = w.bias; a.stats = stats;
@@ -387,11 +439,31 @@ int launch_conv3d_wino(const ConvWeights& w, const Act& x, const Act& y, double*
   // (2 z-slices per workgroup measure the same as 4: the second resident workgroup only pays for
   // the doubled per-workgroup prologue / epilogue; kept as an experiment knob)
   const int tz = variant == 1 ? 2 : 4;
+  // block shapes of a z-slice (conv3d_wino.h): a function of the volume only -- the persistent and the one-role kernel
+  // tile a launch the same way, so their per-block fp32 partial sums of the statistics agree bit for bit
+  a.tiling = wino_tiling(x.D, x.H, x.W, tz);
+  const bool sh = a.tiling.shaped != 0;
+  if (sh && variant == 4 && !tables) {
+    // callers outside a network plan (the op-level test entry): one table per launch shape, built on first use and kept
+    static std::mutex mu;
+    static std::map<std::array<int, 5>, int*> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    int*& dev = cache[{x.N, x.D, x.H, x.W, x.Cp}];
+    if (!dev) {
+      const std::vector<int> host = wino_tables(x.N, x.D, x.H, x.W, x.Cp);
+      JH_CHECK_HIP(hipMalloc(&dev, host.size() * sizeof(int)));
+      JH_CHECK_HIP(hipMemcpy(dev, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    tables = dev;
+  }
+  a.shape_tab = tables;
+  a.tiles = tables ? reinterpret_cast<const WinoTileEntry*>(tables + 3 * kWinoShapeWords) : nullptr;
   if (variant == 4) {
     const int rc = launch_conv3d_wino_pw(a, nr_full, s);
     if (rc >= 0) return rc;                 // -1: too few tiles / one channel pass -> one-role kernel
   }
-  const int blocks = ((x.D + tz - 1) / tz) * ((x.H + kWTY - 1) / kWTY) * ((x.W + kWTX - 1) / kWTX);
+  const int blocks = sh ? a.tiling.slabs * wino_blocks_per_slab(a.tiling)
+                        : ((x.D + tz - 1) / tz) * ((x.H + kWTY - 1) / kWTY) * ((x.W + kWTX - 1) / kWTX);
   // Single-frame-set launches have fewer tiles than the chip has CUs (32 / 128 at 16^3 / 32^3): fewer column
   // blocks per workgroup then, i.e. more workgroups that each repeat the input transform but run a half / a
   // third of the MFMAs.  (nr only partitions the output channels: the fp32 partial sums of the statistics --
@@ -402,11 +474,12 @@ int launch_conv3d_wino(const ConvWeights& w, const Act& x, const Act& y, double*
   const int nr = nr_l;
   dim3 grid(blocks, (nb + nr - 1) / nr, x.N);
   const size_t xbytes = (size_t)4 * 2 * tz * nr * 4 * 64 * sizeof(float);
-  size_t lds = (size_t)((tz + 2) * kWPY * kWPX * 8 + (tz + 2) * 16 * 16 * kWSV) * sizeof(float);
+  size_t lds = (size_t)((tz + 2) * (sh ? 108 : kWPY * kWPX) * 8 + (tz + 2) * 16 * 16 * kWSV) * sizeof(float);
   if (lds < xbytes) lds = xbytes;
   lds += (a.in_stats ? (size_t)2 * a.cin_p : 0) * sizeof(float);
   JH_REQUIRE(lds <= 160 * 1024, "wino LDS");
-#define JH_WINO_CASE(NRV) \
+#define JH_WINO_CASE(NRV)                                                                               \
+  if (nr == NRV && sh) return tz == 4 ? launch_wino_nr<NRV, 4, true>(a, grid, lds, s) : launch_wino_nr<NRV, 2, true>(a, grid, lds, s); \
   if (nr == NRV) return tz == 4 ? launch_wino_nr<NRV, 4>(a, grid, lds, s) : launch_wino_nr<NRV, 2>(a, grid, lds, s);
   JH_WINO_CASE(3) JH_WINO_CASE(2) JH_WINO_CASE(1)
 #undef JH_WINO_CASE

@@ -53,19 +53,22 @@ __device__ __forceinline__ void wg_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 constexpr int kPTZ = 4, kPPZ = kPTZ + 2;
-constexpr int kPNP = kPPZ * kWPY * kWPX;                    // 600 patch pixels
 constexpr int kPVSZ = kPPZ * 16 * 16 * 8;                   // floats per V buffer
-constexpr int kPRS = (kPNP + 8) * 8;                        // floats per R buffer (19 x 64 float4 items)
+// patch pixels per workgroup tile: 6 z-slices of 10 x 10 (the plain grid of 4 x 4-tile blocks) or of up to 18 x 6
+// (SH: the block shapes of conv3d_wino.h), and the floats of an R buffer (19 / 21 rounds of 64 float4 items)
+constexpr int pw_pnp(bool sh) { return kPPZ * (sh ? 108 : kWPY * kWPX); }
+constexpr int pw_prs(bool sh) { return (pw_pnp(sh) + 8 + (sh ? 16 : 0)) * 8; }
 
-struct Tile { int n, nb0, z0, y0, x0; };
+struct Tile { int n, nb0, z0, y0, x0, lc, hlim, wlim; };
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // debug timeline: T(slot) adds the cycles since the previous stamp to slot `slot`
 #define JH_T(slot) do { if (DBG && dbg_on) { const long long _t = __builtin_readcyclecounter(); dbg_acc[slot] += _t - dbg_t; dbg_t = _t; } } while (0)
 }  // namespace
 
-template <int NR, int ABL, bool DBG>
+template <int NR, int ABL, bool DBG, bool SH = false>
 __global__ __launch_bounds__(512) void conv3d_wino_pw_kernel(const WinoArgs a, int tiles_sp,
                                                              int total_tiles) {
+  constexpr int kPNP = pw_pnp(SH), kPRS = pw_prs(SH);
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
   float* R = lds_all;                                       // [2][600][8]
   float* V = R + 2 * kPRS;                                  // [2][6][16][16][8]
@@ -88,15 +91,28 @@ __global__ __launch_bounds__(512) void conv3d_wino_pw_kernel(const WinoArgs a, i
   const int n_my = t_count > wi ? (t_count - wi + per - 1) / per : 0;
   if (n_my == 0) return;
   const int bx_n = (a.W + kWTX - 1) / kWTX, by_n = (a.H + kWTY - 1) / kWTY;
+  const WinoTiling tg = a.tiling;                             // (read from the kernel arguments once)
   auto decode = [&](int k) __attribute__((always_inline)) -> Tile {
     int L = t_start + wi + k * per;
-    const int sp = L % tiles_sp; L /= tiles_sp;
     Tile t;
-    t.n = L % a.N;
-    t.nb0 = (L / a.N) * NR;
-    t.x0 = (sp % bx_n) * kWTX;
-    t.y0 = ((sp / bx_n) % by_n) * kWTY;
-    t.z0 = (sp / (bx_n * by_n)) * kPTZ;
+    if constexpr (SH) {
+      // (shape-major inside a column-block group: a workgroup's stride walk changes shape at most twice per group)
+      // (arithmetic, not a table: a scalar load here costs its latency AND an lgkmcnt(0) wait -- which also waits for
+      //  the LDS operations in flight -- at every tile boundary of every wave: measured 0.65 against 0.57 ms per launch)
+      const int S = a.N * tiles_sp;
+      int g = 0;
+      while (L >= S) { L -= S; ++g; }                       // (column-block groups: one to three; no division)
+      const WinoTile w = wino_decode(tg, a.N, a.H, a.W, kPTZ, L);
+      t.n = w.n; t.nb0 = g * NR; t.z0 = w.z0; t.y0 = w.y0; t.x0 = w.x0; t.lc = w.lc; t.hlim = w.hlim; t.wlim = w.wlim;
+    } else {
+      const int sp = L % tiles_sp; L /= tiles_sp;
+      t.n = L % a.N;
+      t.nb0 = (L / a.N) * NR;
+      t.x0 = (sp % bx_n) * kWTX;
+      t.y0 = ((sp / bx_n) % by_n) * kWTY;
+      t.z0 = (sp / (bx_n * by_n)) * kPTZ;
+      t.lc = 2; t.hlim = a.H; t.wlim = a.W;
+    }
     return t;
   };
 
@@ -130,33 +146,60 @@ __global__ __launch_bounds__(512) void conv3d_wino_pw_kernel(const WinoArgs a, i
     // reference's shipped 72^3 grid): six constant lane masks, six scalar flags per tile.
     int prel[ITER];
     unsigned mz0 = 0, mz1 = 0, my0 = 0, my1 = 0, mx0 = 0, mx1 = 0, mtail = 0;
-    const int rz = a.D % kPTZ ? a.D % kPTZ : kPTZ, ry = a.H % kWTY ? a.H % kWTY : kWTY, rx = a.W % kWTX ? a.W % kWTX : kWTX;
+    const int rz = a.D % kPTZ ? a.D % kPTZ : kPTZ;
+    // SH: the tables above are per block SHAPE (patch 10 x 10, 6 x 18 or 18 x 6 pixels per z-slice; the remainder of
+    // the volume inside the last block of that shape's grid); rebuilt when a tile of another shape comes up -- at most
+    // twice per column-block group, the tile list is shape-major.  TH / TW: voxels of the current shape's block.
+    int shape_lc = -1, TH = kWTY, TW = kWTX;
+    auto shape_tables = [&](auto pw_c, auto ph_c, int ry, int rx) __attribute__((always_inline)) {
+      constexpr int PW = decltype(pw_c)::value, PH = decltype(ph_c)::value;
+      mz0 = mz1 = my0 = my1 = mx0 = mx1 = mtail = 0;
 #pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-      const int idx = lane + it * 64;
-      const int pix = idx >> 1;
-      const int px = pix % kWPX, py = (pix / kWPX) % kWPY, pz = pix / (kWPX * kWPY);
-      prel[it] = (((pz * a.H + py) * a.W + px) * a.cin_p + q * 4) * 4;
-      mz0 |= (pz == 0) << it; mz1 |= (pz > rz) << it;
-      my0 |= (py == 0) << it; my1 |= (py > ry) << it;
-      mx0 |= (px == 0) << it; mx1 |= (px > rx) << it;
-      mtail |= (idx >= kPNP * 2) << it;                     // (beyond the patch: never valid)
+      for (int it = 0; it < ITER; ++it) {
+        const int idx = lane + it * 64;
+        const int pix = idx >> 1;
+        const int px = pix % PW, py = (pix / PW) % PH, pz = pix / (PW * PH);
+        prel[it] = (((pz * a.H + py) * a.W + px) * a.cin_p + q * 4) * 4;
+        mz0 |= (pz == 0) << it; mz1 |= (pz > rz) << it;
+        my0 |= (py == 0) << it; my1 |= (py > ry) << it;
+        mx0 |= (px == 0) << it; mx1 |= (px > rx) << it;
+        mtail |= (idx >= kPPZ * PW * PH * 2) << it;         // (beyond the patch: never valid)
+      }
+    };
+    auto set_shape = [&](int lc) __attribute__((always_inline)) {
+      static_assert(!SH || ITER == kWinoShapeIter, "the host's shape tables cover 21 rounds");
+      shape_lc = lc;
+      TH = 32 >> lc; TW = 2 << lc;
+      const int* tab = a.shape_tab + (lc - 1) * kWinoShapeWords + lane;
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) prel[it] = tab[it * 64];
+      mz0 = tab[ITER * 64]; mz1 = tab[(ITER + 1) * 64]; my0 = tab[(ITER + 2) * 64]; my1 = tab[(ITER + 3) * 64];
+      mx0 = tab[(ITER + 4) * 64]; mx1 = tab[(ITER + 5) * 64]; mtail = tab[(ITER + 6) * 64];
+    };
+    if constexpr (!SH) {
+      shape_tables(std::integral_constant<int, kWPX>{}, std::integral_constant<int, kWPY>{},
+                   a.H % kWTY ? a.H % kWTY : kWTY, a.W % kWTX ? a.W % kWTX : kWTX);
     }
     int pvo[ITER];                                          // byte offsets of the patch to request
     unsigned pinv = 0;                                      // its invalid items
     __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0, 0x00020000);
     auto set_patch = [&](const Tile& t) __attribute__((always_inline)) {
+      if constexpr (SH) {
+        if (t.lc != shape_lc) set_shape(t.lc);
+      }
       const long img_bytes = (long)a.D * a.H * a.W * a.cin_p * 4;
       const long org = ((long)((t.z0 - 1) * a.H + (t.y0 - 1)) * a.W + (t.x0 - 1)) * a.cin_p * 4;
       const char* base = reinterpret_cast<const char*>(a.x) + (long)t.n * img_bytes + org;
       prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, (int)(img_bytes - org), 0x00020000);
       pinv = mtail | (t.z0 == 0 ? mz0 : 0u) | (t.z0 + kPTZ >= a.D ? mz1 : 0u) | (t.y0 == 0 ? my0 : 0u) |
-             (t.y0 + kWTY >= a.H ? my1 : 0u) | (t.x0 == 0 ? mx0 : 0u) | (t.x0 + kWTX >= a.W ? mx1 : 0u);
+             (t.y0 + TH >= a.H ? my1 : 0u) | (t.x0 == 0 ? mx0 : 0u) | (t.x0 + TW >= a.W ? mx1 : 0u);
 #pragma unroll
       for (int it = 0; it < ITER; ++it)
         pvo[it] = (int)(((pinv << (31 - it)) & 0x80000000u) | (unsigned)prel[it]);
     };
     typedef float bf32x4 __attribute__((ext_vector_type(4)));
+    // (SH: a 4 x 4-tile block's patch needs 19 of the 21 rounds; running 19 for those blocks under a uniform branch
+    //  measured the same -- 0.652 against 0.645 ms -- so every block runs the 21 rounds of the largest patch)
     auto issue = [&](int c0) __attribute__((always_inline)) {
 #pragma unroll
       for (int it = 0; it < ITER; ++it) {
@@ -229,18 +272,21 @@ __global__ __launch_bounds__(512) void conv3d_wino_pw_kernel(const WinoArgs a, i
       else commit_mode(std::integral_constant<int, 3>{}, inv, c0, Rd);
     };
     // input transform B^T d B of every (z-slice, tile, channel quad): 6 x 16 x 2 = 192 items
-    auto transform = [&](const float* Rs, float* Vd) __attribute__((always_inline)) {
+    auto transform = [&](const float* Rs, float* Vd, int lc) __attribute__((always_inline)) {
       {
         const int tile = (ht >> 1) & 15, pz = ht >> 5;
-        const int ty = tile >> 2, tx = tile & 3;
-        const float* rb = Rs + ((pz * kWPY + 2 * ty) * kWPX + 2 * tx) * 8 + q * 4;
+        // (tile -> row / column of the block; the patch of the block's shape)
+        constexpr bool SHT = SH;
+        const int ty = SHT ? tile >> lc : tile >> 2, tx = SHT ? tile & ((1 << lc) - 1) : tile & 3;
+        const int PW = SHT ? (2 << lc) + 2 : kWPX, PH = SHT ? (32 >> lc) + 2 : kWPY;
+        const float* rb = Rs + ((pz * PH + 2 * ty) * PW + 2 * tx) * 8 + q * 4;
         f32x2 tr[4][4][2];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           f32x2 d[4][2];
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            const float4 v = *reinterpret_cast<const float4*>(rb + (r * kWPX + c) * 8);
+            const float4 v = *reinterpret_cast<const float4*>(rb + (r * PW + c) * 8);
             d[c][0] = (f32x2){v.x, v.y}; d[c][1] = (f32x2){v.z, v.w};
           }
 #pragma unroll
@@ -282,6 +328,13 @@ __global__ __launch_bounds__(512) void conv3d_wino_pw_kernel(const WinoArgs a, i
     float s1[NR], s2[NR];                                   // statistics of the tile being finished
     const int jq = lane & 3;
     auto finish_half = [&](const Tile& t, int ox) __attribute__((always_inline)) {
+      constexpr bool SHF = SH;
+      // a lane holds tiles 4 kq + r (r = 0..3) of the block: tile -> (row tile >> lc, column tile & cmask); outputs at
+      // y >= hlim or x >= wlim belong to another block (the strips) or lie outside the volume.  (Kept as arithmetic on
+      // the spot: the ten lane constants per shape that would replace the shifts cost registers the kernel does not
+      // have -- 0.68 against 0.60 ms per launch.)
+      const int lc = SHF ? t.lc : 2, cmask = (1 << lc) - 1;
+      const int hlim = SHF ? t.hlim : a.H, wlim = SHF ? t.wlim : a.W;
       float* yb = a.y + (size_t)t.n * a.D * a.H * a.W * a.cout_p;
       const int oz = t.z0 + sw;
 #pragma unroll
@@ -301,11 +354,11 @@ __global__ __launch_bounds__(512) void conv3d_wino_pw_kernel(const WinoArgs a, i
             v[0] = p1.x - p2.x - p3.x; v[1] = p1.y - p2.y - p3.y;
             v[2] = p1.z - p2.z - p3.z; v[3] = p1.w - p2.w - p3.w;
           }
-          const int yy = t.y0 + 2 * kq + oy;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             v[r] += bvl;
-            if (ch_ok && oz < a.D && yy < a.H && t.x0 + 2 * r + ox < a.W) {
+            const int tl = 4 * kq + r;
+            if (ch_ok && oz < a.D && t.y0 + 2 * (tl >> lc) + oy < hlim && t.x0 + 2 * (tl & cmask) + ox < wlim) {
               s1[nr] += v[r];
               s2[nr] += v[r] * v[r];
             }
@@ -317,9 +370,10 @@ __global__ __launch_bounds__(512) void conv3d_wino_pw_kernel(const WinoArgs a, i
             x = (jq & 2) ? v[0] : v[2]; y = quad_xor2(x); if (jq & 2) v[0] = y; else v[2] = y;
             x = (jq & 2) ? v[1] : v[3]; y = quad_xor2(x); if (jq & 2) v[1] = y; else v[3] = y;
           }
-          const int xx = t.x0 + 2 * jq + ox;
+          const int tj = 4 * kq + jq;                       // (after the transpose: tile 4 kq + jq)
+          const int yy = t.y0 + 2 * (tj >> lc) + oy, xx = t.x0 + 2 * (tj & cmask) + ox;
           const int c0 = (t.nb0 + nr) * 16 + (mrow & ~3);
-          if (c0 < a.cout_p && oz < a.D && yy < a.H && xx < a.W)
+          if (c0 < a.cout_p && oz < a.D && yy < hlim && xx < wlim)
             *reinterpret_cast<float4*>(yb + ((size_t)(oz * a.H + yy) * a.W + xx) * a.cout_p + c0) =
                 make_float4(v[0], v[1], v[2], v[3]);
         }
@@ -384,7 +438,7 @@ __global__ __launch_bounds__(512) void conv3d_wino_pw_kernel(const WinoArgs a, i
         commit(pm, 8, R1);
         issue(16);                                          // P >= 3
       } else {
-        transform(R0, V);
+        transform(R0, V, cur.lc);
       }
       wg_barrier();                                         // P1: V[0], R[1] complete
       wg_barrier();                                         // P2 (kept: the matrix waves count three)
@@ -410,7 +464,7 @@ __global__ __launch_bounds__(512) void conv3d_wino_pw_kernel(const WinoArgs a, i
             JH_T(2);
           } else {
             if ((p + 1 < P || has_next) && ABL != 2)
-              transform((g + p + 1) & 1 ? R1 : R0, V + ((g + p + 1) & 1) * kPVSZ);
+              transform((g + p + 1) & 1 ? R1 : R0, V + ((g + p + 1) & 1) * kPVSZ, p + 1 < P ? cur.lc : nxt.lc);
             JH_T(4);
           }
           JH_T(3);
@@ -576,9 +630,9 @@ __global__ __launch_bounds__(512) void conv3d_wino_pw_kernel(const WinoArgs a, i
   __syncthreads();                                          // Bf
 }
 
-template <int NR, int ABL = 0, bool DBG = false>
+template <int NR, int ABL = 0, bool DBG = false, bool SH = false>
 static int launch_pw_nr(const WinoArgs& a, int grid, size_t lds, int tiles_sp, int total, hipStream_t s) {
-  auto kern = conv3d_wino_pw_kernel<NR, ABL, DBG>;
+  auto kern = conv3d_wino_pw_kernel<NR, ABL, DBG, SH>;
   static bool big = false;
   if (!big) {
     JH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -618,13 +672,22 @@ int launch_conv3d_wino_pw(const WinoArgs& a, int nr, hipStream_t s) {
     if (cus < 8) return -1;
   }
   const int nb = a.cout_p16 / 16;
-  const int tiles_sp = ((a.D + kPTZ - 1) / kPTZ) * ((a.H + kWTY - 1) / kWTY) * ((a.W + kWTX - 1) / kWTX);
+  const bool sh = a.tiling.shaped != 0;
+  const int tiles_sp = sh ? a.tiling.slabs * wino_blocks_per_slab(a.tiling)
+                          : ((a.D + kPTZ - 1) / kPTZ) * ((a.H + kWTY - 1) / kWTY) * ((a.W + kWTX - 1) / kWTX);
   const int groups = (nb + nr - 1) / nr;
   const long total = (long)tiles_sp * groups * a.N;
   if (a.cin_p < 24 || total < 2L * cus || total > (1L << 30)) return -1;       // P >= 3
   if ((long)a.D * a.H * a.W * a.cin_p * 4 + (long)(a.H + 1) * a.W * a.cin_p * 4 + 64 >= (1L << 31)) return -1;
   JH_REQUIRE((size_t)4 * kPTZ * nr * 64 * 4 <= (size_t)kPVSZ, "wino (persistent) dump buffer");
-  const size_t lds = (size_t)(2 * kPRS + 2 * kPVSZ + 4 * nr * 16 * 2 + 2 * a.cin_p) * sizeof(float);
+  const size_t lds = (size_t)(2 * pw_prs(sh) + 2 * kPVSZ + 4 * nr * 16 * 2 + 2 * a.cin_p) * sizeof(float);
+  JH_REQUIRE(lds <= 160 * 1024, "wino (persistent) LDS");
+  if (sh) {       // (the volumes with remainder strips: no experiment variants)
+    JH_REQUIRE(a.shape_tab != nullptr, "wino (persistent) shape tables");
+    if (nr == 3) return launch_pw_nr<3, 0, false, true>(a, cus, lds, tiles_sp, (int)total, s);
+    if (nr == 2) return launch_pw_nr<2, 0, false, true>(a, cus, lds, tiles_sp, (int)total, s);
+    return launch_pw_nr<1, 0, false, true>(a, cus, lds, tiles_sp, (int)total, s);
+  }
   const int abl = JH_ENV_KNOB("JH_WS_ABL");
   if (nr == 3 && abl == 1) return launch_pw_nr<3, 1>(a, cus, lds, tiles_sp, (int)total, s);
   if (nr == 3 && abl == 2) return launch_pw_nr<3, 2>(a, cus, lds, tiles_sp, (int)total, s);

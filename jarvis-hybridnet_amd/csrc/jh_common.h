@@ -299,8 +299,9 @@ struct NodeArgs;
 int launch_bifpn_node(const NodeArgs& a, hipStream_t s);
 int pack_wino_weights(int cin, int cout, const float* w, const float* b, ConvWeights* out);
 int wino_variant_from_env();
+// tables: the persistent kernel's tables for this launch shape (wino_tables, uploaded by the plan) or nullptr
 int launch_conv3d_wino(const ConvWeights& w, const Act& x, const Act& y, double* stats, hipStream_t s,
-                       const InNorm* in, int variant = 4);
+                       const InNorm* in, int variant = 4, const int* tables = nullptr);
 // split-bf16 form of the same convolution (csrc/conv3d_bf16x3.hip; precision mode bf16x3)
 int pack_bf16x3_weights(int cin, int cout, const float* w, const float* b, ConvWeights* out);
 int launch_conv3d_bf16x3(const ConvWeights& w, const Act& x, const Act& y, double* stats, hipStream_t s,

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include "nets.h"
 #include "bifpn_node.h"
+#include "conv3d_wino.h"
 
 namespace jh {
 
@@ -152,12 +153,24 @@ int Plan::add_conv(const ParamMap& pm, const ConvDesc& d, const std::string& wke
   const double taps_per_out = (d.ostride > 1) ? (double)taps / d.nphase : (double)taps;
   const double flops = 2.0 * opix * d.cin * d.cout * taps_per_out;
   const double bytes = 4.0 * ((double)x.N * x.pixels() * d.cin + opix * d.cout + (double)d.cin * d.cout * taps);
+  // Winograd on a volume with remainder strips (e.g. 36^3 / 18^3 of the shipped 72^3 grid): the persistent kernel's
+  // tile table, built and uploaded here, at plan-build time (csrc/conv3d_wino.h)
+  const int* wino_tiles = nullptr;
+  if (wino && !b3) {
+    const std::vector<int> tt = wino_tables(y.N, y.D, y.H, y.W, x.Cp);
+    if (!tt.empty()) {
+      void* dev = nullptr;
+      if (alloc(&dev, tt.size() * sizeof(int))) return 1;
+      JH_CHECK_HIP(hipMemcpy(dev, tt.data(), tt.size() * sizeof(int), hipMemcpyHostToDevice));
+      wino_tiles = static_cast<const int*>(dev);
+    }
+  }
   char nm[96];
   snprintf(nm, sizeof nm, "conv%dd_k%ds%d%s_%dx%d@%d", d.nd, d.ostride > 1 ? (d.nd == 2 ? 4 : 2) : d.k,
            d.ostride > 1 ? 2 : d.stride, d.ostride > 1 ? (d4b ? "Tbf16x3" : "T") : (b3 || xb ? "bf16x3" : (wino ? "wino" : "")), d.cin, d.cout, y.W);
   push(nm, flops, bytes,
        [this, d, cw, x, y, gate, want_stats, off, in_stats_off, in_inv, in_act, wino, wino_variant, b3, d4b, xb,
-        sev = se ? *se : SeGate(), se_pool_off](hipStream_t s) {
+        wino_tiles, sev = se ? *se : SeGate(), se_pool_off](hipStream_t s) {
     InNorm in;
     if (in_stats_off >= 0) { in.stats = sc((size_t)in_stats_off); in.inv = in_inv; in.act = in_act; }
     SeGate seg = sev;
@@ -165,7 +178,7 @@ int Plan::add_conv(const ParamMap& pm, const ConvDesc& d, const std::string& wke
     if (xb) return launch_conv_bf16x3(d, cw, x, y, want_stats ? sc(off) : nullptr, s, &in);
     if (d4b) return launch_deconv4_bf16x3(cw, x, y, s, &in);
     if (b3) return launch_conv3d_bf16x3(cw, x, y, want_stats ? sc(off) : nullptr, s, &in);
-    if (wino) return launch_conv3d_wino(cw, x, y, want_stats ? sc(off) : nullptr, s, &in, wino_variant);
+    if (wino) return launch_conv3d_wino(cw, x, y, want_stats ? sc(off) : nullptr, s, &in, wino_variant, wino_tiles);
     return launch_conv(d, cw, x, y, gate, want_stats ? sc(off) : nullptr, s, &in, se_pool_off >= 0 ? &seg : nullptr);
   });
   return 0;
