@@ -296,7 +296,10 @@ struct CubeArgs {
 
 template <int Q, int CI, int NT>
 __global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
-  constexpr int VPT = CI * 256 / NT;                // voxels per thread (groups of 4 j-rows x 16 k per wave)
+  // voxels per thread: a wave's group g = w * VPT + v is the i-plane g % CI and the j-rows 4 (g / CI) .. + 3 of the
+  // cube, 16 k each -- j-row groups vary slowest over the waves, so in a cube that is ragged along j (72 = 4.5 x 16)
+  // the waves without a voxel inside the grid are spread evenly over the SIMDs and skip the tap arithmetic
+  constexpr int VPT = CI * 256 / NT;
   constexpr int NI = CI / 2 + 2, NTAB = NI * kTabJ * kTabK;
   constexpr int TPT = (NTAB + NT - 1) / NT;         // table entries staged per thread
   constexpr int JPB = Q * 16;                       // bytes per heatmap pixel in memory
@@ -311,7 +314,9 @@ __global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
   const BlockId bid = xcd_block();
   const int t = bid.y, tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int G = a.G, Gh = G >> 1, C = a.C, hs = a.hs;
-  const int nck = G / kCubeK, ncj = G / kCubeJ;
+  // (G not a multiple of 16 -- the reference's shipped 72^3 grid: the last cube along j and k is ragged; its voxels past
+  //  the grid are computed from clamped table entries like any others and dropped at the stores)
+  const int nck = (G + kCubeK - 1) / kCubeK, ncj = (G + kCubeJ - 1) / kCubeJ;
   const int cube = (int)bid.x;
   const int ck = cube % nck, cj = (cube / nck) % ncj, ci = cube / (nck * ncj);
   const int I0 = ci * CI, J0 = cj * kCubeJ, K0 = ck * kCubeK;
@@ -331,7 +336,7 @@ __global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
     up2_axis(K0 + (lane & 15), Gh, &k0, &k1, &wk0, &wk1);
 #pragma unroll
     for (int g = 0; g < VPT; ++g) {
-      const int gi = w * VPT + g, il = gi >> 2, jl = ((gi & 3) << 2) + (lane >> 4);
+      const int gi = w * VPT + g, il = gi % CI, jl = ((gi / CI) << 2) + (lane >> 4);
       int i0, i1, j0, j1;
       up2_axis(I0 + il, Gh, &i0, &i1, &wi0[g], &wi1[g]);
       up2_axis(J0 + jl, Gh, &j0, &j1, &wj0[g], &wj1[g]);
@@ -447,9 +452,10 @@ __global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
       if (a.idx_out) {
         int ln = lane;
         asm volatile("" : "+v"(ln));
-        const int gi = w * VPT + v, il = gi >> 2, jl = ((gi & 3) << 2) + (ln >> 4);
-        a.idx_out[((size_t)(t * C + c)) * nvox + ((size_t)(I0 + il) * G + (J0 + jl)) * G + K0 + (ln & 15)] =
-            iv * hs + iu;
+        const int gi = w * VPT + v, il = gi % CI, jl = ((gi / CI) << 2) + (ln >> 4);
+        if (J0 + jl < G && K0 + (ln & 15) < G)
+          a.idx_out[((size_t)(t * C + c)) * nvox + ((size_t)(I0 + il) * G + (J0 + jl)) * G + K0 + (ln & 15)] =
+              iv * hs + iu;
       }
       const int hx = iu - 1 + a.heat_pad, hy = iv - 1 + a.heat_pad;
       const int px = hx - g.x0, py = hy - g.y0;
@@ -514,7 +520,9 @@ __global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
   if (!gc.big) load_patch(0, cam_c, gc);
   int4 box_n = box(1);                                // (a box is fetched one camera ahead of its use)
   int off_c[VPT];
-  tap_offsets(0, gc, off_c);
+  // (uniform per wave: does any of this wave's j-row groups lie inside the grid?)
+  const bool wave_in = J0 + 4 * ((w * VPT) / CI) < G;
+  if (wave_in) tap_offsets(0, gc, off_c);
   __syncthreads();
 
   float4 acc[VPT][Q];
@@ -540,7 +548,7 @@ __global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
     // gather camera c: every lane reads the Q quads of its own voxels' pixels
     const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cam_base(cam_c)), 0,
                                                                            plane_bytes, 0x00020000);
-    if (!(a.abl & 2))
+    if (!(a.abl & 2) && wave_in)
 #pragma unroll
     for (int v = 0; v < VPT; ++v) {
       const int o = off_c[v] >= 0 ? off_c[v] : kZeroOff;
@@ -554,6 +562,7 @@ __global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
     }
     // taps that are not in LDS (a box over the LDS budget; never seen otherwise): from global memory.
     // Those lanes added the zero pixel above, so the camera order of the sum is unchanged.
+    if (wave_in)
 #pragma unroll
     for (int v = 0; v < VPT; ++v) {
       if (__builtin_amdgcn_ballot_w64(off_c[v] < 0) != 0) {                  // uniform per wave
@@ -567,7 +576,10 @@ __global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
         }
       }
     }
-    if (more && !(a.abl & 4)) tap_offsets(c + 1, gn, off_c);          // (reads table (c+1) & 1; off_c of camera c is spent)
+    // (tried, round 5: half of the waves interpolating camera c+1's taps BEFORE they gather camera c, so that the
+    //  workgroup's waves do not hit the LDS pipe and then the vector ALU in lock step -- as a wave-uniform branch over two
+    //  copies of this body it takes the kernel from 116 to 128 registers with 50 spills)
+    if (more && !(a.abl & 4) && wave_in) tap_offsets(c + 1, gn, off_c);          // (reads table (c+1) & 1; off_c of camera c is spent)
     // table of camera c+2 over the table of camera c (read for the last time one iteration ago)
 #pragma unroll
     for (int e = 0; e < TPT; ++e)
@@ -609,15 +621,16 @@ __global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
       *reinterpret_cast<float4*>(park + (lane_late * Q + q) * 16) = r;
     }
     // (the same wave wrote and reads: the LDS operations of a wave complete in order, no barrier)
-    const int gi = w * VPT + v, il = gi >> 2;
+    const int gi = w * VPT + v, il = gi % CI;
 #pragma unroll
     for (int n = 0; n < Q; ++n) {
       const int ch = n * 64 + lane_late;              // chunk of this group's 64 * Q
       const int run = ch / kRunChunks, within = ch - run * kRunChunks;
-      const int jl = ((gi & 3) << 2) + run;
+      const int jl = ((gi / CI) << 2) + run;
       const size_t vox0 = ((size_t)(I0 + il) * G + (J0 + jl)) * G + K0;
       const float4 r = *reinterpret_cast<const float4*>(park + ch * 16);
-      if (!(a.abl & 8))
+      // (ragged last cubes: rows j >= G and, inside a run, voxels k >= G are not part of the grid)
+      if (!(a.abl & 8) && J0 + jl < G && K0 + within / Q < G)
         *reinterpret_cast<float4*>(a.vol + ((size_t)t * nvox + vox0) * (JPB / 4) + within * 4) = r;
     }
   }
@@ -636,7 +649,7 @@ static int launch_cube(const CubeArgs& a, int T, hipStream_t s) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if (devid >= 0 && devid < 64) big[devid].store(true, std::memory_order_release);
   }
-  const int cubes = (a.G / CI) * (a.G / kCubeJ) * (a.G / kCubeK);
+  const int cubes = (a.G / CI) * ((a.G + kCubeJ - 1) / kCubeJ) * ((a.G + kCubeK - 1) / kCubeK);
   hipLaunchKernelGGL(kern, dim3(cubes, T), dim3(NT), (size_t)kCubePatchOff(CI) + 2 * a.patch_bytes, s, a);
   JH_CHECK_HIP(hipGetLastError());
   return 0;
@@ -661,8 +674,10 @@ int launch_reproject(const float* cam, const float* intr, const float* dist, con
   hipLaunchKernelGGL(repro_coarse_kernel, dim3((nvc + 255) / 256, C, T), dim3(256), 0, s, cal,
                      center3d, center_hm, coarse, C, Gh, spacing, hs);
   JH_CHECK_HIP(hipGetLastError());
-  // cube form: G a multiple of 16, at most 32 channels (JH_REPRO_CUBE=0: the voxel-row form below)
-  if (G % 16 == 0 && Jp <= 32 && JH_ENV_KNOB("JH_REPRO_CUBE") != 0) {
+  // cube form: G a multiple of 8 (the cubes' thickness; j and k may leave a ragged last cube: 72 = 4.5 x 16), at most
+  // 32 channels (JH_REPRO_CUBE=0: the voxel-row form below; JH_REPRO_CUBE=16: only grids that are multiples of 16)
+  if (G % 8 == 0 && G >= 16 && Jp <= 32 && JH_ENV_KNOB("JH_REPRO_CUBE") != 0 &&
+      (G % 16 == 0 || JH_ENV_KNOB("JH_REPRO_CUBE") != 16)) {
     CubeArgs ca{coarse, heat, vol, idx_out, C, G, hs, heat_pad, div255, 0, 0, lay, 0};
     ca.abl = std::max(0, JH_ENV_KNOB("JH_REPRO_ABL"));
     const int Q = Jp / 4;
