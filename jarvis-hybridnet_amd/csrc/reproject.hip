@@ -98,6 +98,11 @@ __device__ __forceinline__ void up2_axis(int d, int Gh, int* i0, int* i1, float*
 __device__ __forceinline__ float lerp_ref(float p0, float p1, float w0, float w1) {
   return __fmaf_rn(p0, w0, __fmul_rn(p1, w1));
 }
+// ... of a (u, v) pair at once: v_pk_mul_f32 + v_pk_fma_f32, the same two IEEE operations per component
+typedef float rp2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ rp2 lerp_ref2(rp2 p0, rp2 p1, float w0, float w1) {
+  return __builtin_elementwise_fma(p0, (rp2){w0, w0}, p1 * (rp2){w1, w1});
+}
 
 // Latency structure (the kernel is latency-, not bandwidth-bound): a workgroup owns 256
 // consecutive fine voxels.  (1) ONE round trip stages the coarse (u, v) table rows those
@@ -435,19 +440,18 @@ __global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
     const float2* cz = ctab + (c & 1) * NTAB;
 #pragma unroll
     for (int v = 0; v < VPT; ++v) {
-      const float2* p = cz + cidx[v];
-      const float2 p000 = p[0], p001 = p[1];
-      const float2 p010 = p[kTabK], p011 = p[kTabK + 1];
-      const float2 p100 = p[kTabJ * kTabK], p101 = p[kTabJ * kTabK + 1];
-      const float2 p110 = p[kTabJ * kTabK + kTabK], p111 = p[kTabJ * kTabK + kTabK + 1];
-      const float u00 = lerp_ref(p000.x, p001.x, wk0, wk1), u01 = lerp_ref(p010.x, p011.x, wk0, wk1);
-      const float u10 = lerp_ref(p100.x, p101.x, wk0, wk1), u11 = lerp_ref(p110.x, p111.x, wk0, wk1);
-      const float v00 = lerp_ref(p000.y, p001.y, wk0, wk1), v01 = lerp_ref(p010.y, p011.y, wk0, wk1);
-      const float v10 = lerp_ref(p100.y, p101.y, wk0, wk1), v11 = lerp_ref(p110.y, p111.y, wk0, wk1);
-      const float u0 = lerp_ref(u00, u01, wj0[v], wj1[v]), u1 = lerp_ref(u10, u11, wj0[v], wj1[v]);
-      const float v0 = lerp_ref(v00, v01, wj0[v], wj1[v]), v1 = lerp_ref(v10, v11, wj0[v], wj1[v]);
-      const float uu = lerp_ref(u0, u1, wi0[v], wi1[v]);
-      const float vv = lerp_ref(v0, v1, wi0[v], wi1[v]);
+      // (u, v) pairs through packed fp32 instructions: half the vector instructions of the scalar form, the same
+      // IEEE operation per component (W (k) innermost, then H (j), then D (i))
+      const rp2* p = reinterpret_cast<const rp2*>(cz + cidx[v]);
+      const rp2 p000 = p[0], p001 = p[1];
+      const rp2 p010 = p[kTabK], p011 = p[kTabK + 1];
+      const rp2 p100 = p[kTabJ * kTabK], p101 = p[kTabJ * kTabK + 1];
+      const rp2 p110 = p[kTabJ * kTabK + kTabK], p111 = p[kTabJ * kTabK + kTabK + 1];
+      const rp2 c00 = lerp_ref2(p000, p001, wk0, wk1), c01 = lerp_ref2(p010, p011, wk0, wk1);
+      const rp2 c10 = lerp_ref2(p100, p101, wk0, wk1), c11 = lerp_ref2(p110, p111, wk0, wk1);
+      const rp2 d0 = lerp_ref2(c00, c01, wj0[v], wj1[v]), d1 = lerp_ref2(c10, c11, wj0[v], wj1[v]);
+      const rp2 uv = lerp_ref2(d0, d1, wi0[v], wi1[v]);
+      const float uu = uv[0], vv = uv[1];
       const int iu = (int)__fdiv_rn(uu, 2.f), iv = (int)__fdiv_rn(vv, 2.f);
       if (a.idx_out) {
         int ln = lane;
@@ -525,12 +529,18 @@ __global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
   if (wave_in) tap_offsets(0, gc, off_c);
   __syncthreads();
 
-  float4 acc[VPT][Q];
+  rp2 acc[VPT][Q][2];                                 // (channel pairs: v_pk_add_f32, half the additions' instructions)
 #pragma unroll
   for (int v = 0; v < VPT; ++v)
 #pragma unroll
-    for (int q = 0; q < Q; ++q) acc[v][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < Q; ++q) { acc[v][q][0] = (rp2){0.f, 0.f}; acc[v][q][1] = (rp2){0.f, 0.f}; }
 
+  float2 tnext[TPT];                                  // table of camera c+2 at the top of iteration c
+#pragma unroll
+  for (int e = 0; e < TPT; ++e) {
+    tnext[e] = make_float2(0.f, 0.f);
+    if (2 < C && e * NT + tid < NTAB) tnext[e] = a.coarse[(size_t)(t * C + 2) * nvox_c + ctab_src[e]];
+  }
   for (int c = 0; c < ((a.abl & 32) ? 1 : C); ++c) {
     // camera c+1: box, patch in flight into the other buffer; camera c+2: table entry in flight
     Geo gn = gc;
@@ -541,10 +551,16 @@ __global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
       box_n = box(c + 2);
       if (!gn.big && !(a.abl & 1)) load_patch(c + 1, cam_n, gn);
     }
+    // table of camera c+3 requested now, committed at the END OF THE NEXT iteration (as camera (c+1)+2): a table entry
+    // has two iterations to arrive.  (Requested and committed inside one iteration, its round trip was the floor under
+    // every camera step: with patch loads, LDS gather and tap arithmetic ablated the kernel still took 0.57 ms, 0.35
+    // without these loads.)
     float2 tv[TPT];
 #pragma unroll
-    for (int e = 0; e < TPT; ++e)
-      if (c + 2 < C && e * NT + tid < NTAB && !(a.abl & 16)) tv[e] = a.coarse[(size_t)(t * C + c + 2) * nvox_c + ctab_src[e]];
+    for (int e = 0; e < TPT; ++e) {
+      tv[e] = tnext[e];
+      if (c + 3 < C && e * NT + tid < NTAB && !(a.abl & 16)) tnext[e] = a.coarse[(size_t)(t * C + c + 3) * nvox_c + ctab_src[e]];
+    }
     // gather camera c: every lane reads the Q quads of its own voxels' pixels
     const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cam_base(cam_c)), 0,
                                                                            plane_bytes, 0x00020000);
@@ -557,7 +573,8 @@ __global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
       for (int q = 0; q < Q; ++q) h[q] = *reinterpret_cast<const gf4*>(smem + o + q * 16);
 #pragma unroll
       for (int q = 0; q < Q; ++q) {
-        acc[v][q].x += h[q][0]; acc[v][q].y += h[q][1]; acc[v][q].z += h[q][2]; acc[v][q].w += h[q][3];
+        acc[v][q][0] += __builtin_shufflevector(h[q], h[q], 0, 1);
+        acc[v][q][1] += __builtin_shufflevector(h[q], h[q], 2, 3);
       }
     }
     // taps that are not in LDS (a box over the LDS budget; never seen otherwise): from global memory.
@@ -571,7 +588,8 @@ __global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
           for (int q = 0; q < Q; ++q) {
             const gf4 h = __builtin_bit_cast(gf4, __builtin_amdgcn_raw_buffer_load_b128(
                                                       rs_c, (off_c[v] & 0x7fffffff) + q * 16, 0, 0));
-            acc[v][q].x += h[0]; acc[v][q].y += h[1]; acc[v][q].z += h[2]; acc[v][q].w += h[3];
+            acc[v][q][0] += __builtin_shufflevector(h, h, 0, 1);
+            acc[v][q][1] += __builtin_shufflevector(h, h, 2, 3);
           }
         }
       }
@@ -594,9 +612,11 @@ __global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
   // ---- mean over cameras, / 255 (see repro_gather_kernel); a lane stores its voxels' Jp channels ----
   const float fc = (float)C;
   const float rfc = __fdiv_rn(1.f, fc), r255 = __fdiv_rn(1.f, 255.f);
-  auto divc = [](float x, float cc, float rc) __attribute__((always_inline)) {
-    const float q = __fmul_rn(x, rc);
-    return __fmaf_rn(__fmaf_rn(-q, cc, x), rc, q);
+  // (packed: q = x rc, r = fma(-q, c, x), q' = fma(r, rc, q) on channel pairs)
+  auto divc2 = [](rp2 x, float cc, float rc) __attribute__((always_inline)) {
+    const rp2 c2 = (rp2){cc, cc}, r2 = (rp2){rc, rc};
+    const rp2 q = x * r2;
+    return __builtin_elementwise_fma(__builtin_elementwise_fma(-q, c2, x), r2, q);
   };
   // The results leave through LDS (the patch buffers are free now): a lane parks the Jp channels of
   // its voxels, then the wave streams its VPT * 4 runs of 16 voxels -- 16 * Jp * 4 contiguous bytes
@@ -610,15 +630,13 @@ __global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
   for (int v = 0; v < VPT; ++v) {
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-      float4 r;
-      r.x = divc(acc[v][q].x, fc, rfc); r.y = divc(acc[v][q].y, fc, rfc);
-      r.z = divc(acc[v][q].z, fc, rfc); r.w = divc(acc[v][q].w, fc, rfc);
+      rp2 lo = divc2(acc[v][q][0], fc, rfc), hi = divc2(acc[v][q][1], fc, rfc);
       if (a.div255) {
-        r.x = divc(r.x, 255.f, r255); r.y = divc(r.y, 255.f, r255);
-        r.z = divc(r.z, 255.f, r255); r.w = divc(r.w, 255.f, r255);
+        lo = divc2(lo, 255.f, r255);
+        hi = divc2(hi, 255.f, r255);
       }
       // voxel `lane` of group v = run lane / 16 (a j-row), position lane % 16 inside the run
-      *reinterpret_cast<float4*>(park + (lane_late * Q + q) * 16) = r;
+      *reinterpret_cast<float4*>(park + (lane_late * Q + q) * 16) = make_float4(lo[0], lo[1], hi[0], hi[1]);
     }
     // (the same wave wrote and reads: the LDS operations of a wave complete in order, no barrier)
     const int gi = w * VPT + v, il = gi % CI;
