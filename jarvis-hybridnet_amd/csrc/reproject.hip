@@ -299,6 +299,32 @@ struct CubeArgs {
                  // 4 no tap interpolation after camera 0, 8 no stores, 16 no table prefetch
 };
 
+// raw LDS reads of Q consecutive 16-byte words (see repro_cube_kernel: invisible to the compiler's wait-count pass)
+typedef float cube_f4 __attribute__((ext_vector_type(4)));
+template <int Q>
+__device__ __forceinline__ void lds_read_quads(cube_f4 (&h)[Q], unsigned addr) {
+  if constexpr (Q == 2)
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(h[0]), "=&v"(h[1]) : "v"(addr));
+  else if constexpr (Q == 4)
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\t"
+                 "ds_read_b128 %3, %4 offset:48\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(h[0]), "=&v"(h[1]), "=&v"(h[2]), "=&v"(h[3]) : "v"(addr));
+  else if constexpr (Q == 6)
+    asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:16\n\tds_read_b128 %2, %6 offset:32\n\t"
+                 "ds_read_b128 %3, %6 offset:48\n\tds_read_b128 %4, %6 offset:64\n\tds_read_b128 %5, %6 offset:80\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(h[0]), "=&v"(h[1]), "=&v"(h[2]), "=&v"(h[3]), "=&v"(h[4]), "=&v"(h[5]) : "v"(addr));
+  else {
+    static_assert(Q == 8, "channel quads of the cube gather");
+    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:32\n\t"
+                 "ds_read_b128 %3, %8 offset:48\n\tds_read_b128 %4, %8 offset:64\n\tds_read_b128 %5, %8 offset:80\n\t"
+                 "ds_read_b128 %6, %8 offset:96\n\tds_read_b128 %7, %8 offset:112\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(h[0]), "=&v"(h[1]), "=&v"(h[2]), "=&v"(h[3]), "=&v"(h[4]), "=&v"(h[5]), "=&v"(h[6]), "=&v"(h[7])
+                 : "v"(addr));
+  }
+}
+
 template <int Q, int CI, int NT>
 __global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
   // voxels per thread: a wave's group g = w * VPT + v is the i-plane g % CI and the j-rows 4 (g / CI) .. + 3 of the
@@ -314,14 +340,26 @@ __global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
   constexpr int kZeroOff = 2 * NTAB * 8;            // one all-zero pixel (the virtual border)
   constexpr int kGeoOff = kZeroOff + 256;           // [C] int4 (x0, y0, pw, ph): the patch boxes of all cameras
   constexpr int kPatchOff = kCubePatchOff(CI);
-  typedef float gf4 __attribute__((ext_vector_type(4)));
+  typedef cube_f4 gf4;
+  // The LDS reads of the camera loop -- tap interpolation tables and the gather itself -- are raw ds_read instructions
+  // (inline asm, waited for explicitly): the compiler cannot tell that the patch DMA in flight (global_load_lds into the
+  // OTHER patch buffer) does not alias them and puts `s_waitcnt vmcnt(0)` in front of the first LDS read it emits after
+  // a DMA -- a wave then waits for the patch of camera c+1 it has just requested BEFORE it gathers camera c, and the round
+  // trip is exposed in every camera step instead of running under the step's arithmetic.
+  typedef __attribute__((address_space(3))) unsigned char lds_u8;
+  const unsigned lds0 = (unsigned)(size_t)(lds_u8*)smem;
 
-  const BlockId bid = xcd_block();
-  const int t = bid.y, tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int G = a.G, Gh = G >> 1, C = a.C, hs = a.hs;
   // (G not a multiple of 16 -- the reference's shipped 72^3 grid: the last cube along j and k is ragged; its voxels past
   //  the grid are computed from clamped table entries like any others and dropped at the stores)
   const int nck = (G + kCubeK - 1) / kCubeK, ncj = (G + kCubeJ - 1) / kCubeJ;
+  // (tried, round 5: a PERSISTENT form -- one workgroup per CU walking the (frame, cube) list, so that the stores of cube k
+  //  drain under the prologue of cube k+1 instead of holding the CU's LDS until the workgroup has ended: 3 % faster than
+  //  one workgroup per cube inside the same binary, but the loop costs 10 registers -- 128 with 11 spills -- and the
+  //  binary 8 %: 0.741 against 0.685 ms)
+  const BlockId bid = xcd_block();
+  const int t = bid.y;
   const int cube = (int)bid.x;
   const int ck = cube % nck, cj = (cube / nck) % ncj, ci = cube / (nck * ncj);
   const int I0 = ci * CI, J0 = cj * kCubeJ, K0 = ck * kCubeK;
@@ -436,41 +474,62 @@ __global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
   };
   // where the taps of camera c (geometry g) of this lane's voxels are: an LDS byte offset (>= 0) or
   // bit 31 + the byte offset inside the camera's heatmap (that lane then reads global memory)
+  // Tap of voxel v in camera c, in two halves so that the camera loop can put ONE LDS round trip under both its table
+  // reads and the gather of the previous camera: tap_request issues the four ds_read2_b64 of the table entries (cidx,
+  // cidx + 1 | + kTabK | + kTabJ kTabK | + both; offsets in 8-byte units) WITHOUT waiting, tap_finish interpolates
+  // (packed fp32: (u, v) pairs, the same IEEE operation per component as the scalar form; W (k) innermost, then H (j),
+  // then D (i)) and turns the index into an LDS / global offset.
+  struct TapRaw { gf4 t0, t1, t2, t3; };
+  auto tap_request = [&](int c, int v, TapRaw& r) __attribute__((always_inline)) {
+    const unsigned ta = lds0 + (unsigned)(((c & 1) * NTAB + cidx[v]) * 8);
+    asm volatile("ds_read2_b64 %0, %4 offset0:0 offset1:1\n\t"
+                 "ds_read2_b64 %1, %4 offset0:%5 offset1:%6\n\t"
+                 "ds_read2_b64 %2, %4 offset0:%7 offset1:%8\n\t"
+                 "ds_read2_b64 %3, %4 offset0:%9 offset1:%10"
+                 : "=&v"(r.t0), "=&v"(r.t1), "=&v"(r.t2), "=&v"(r.t3)
+                 : "v"(ta), "n"(kTabK), "n"(kTabK + 1), "n"(kTabJ * kTabK), "n"(kTabJ * kTabK + 1),
+                   "n"(kTabJ * kTabK + kTabK), "n"(kTabJ * kTabK + kTabK + 1));
+  };
+  auto tap_wait = [&](TapRaw& r) __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.t0), "+v"(r.t1), "+v"(r.t2), "+v"(r.t3));
+  };
+  auto tap_finish = [&](int c, const Geo& g, int v, const TapRaw& r) __attribute__((always_inline)) -> int {
+    const rp2 p000 = (rp2){r.t0[0], r.t0[1]}, p001 = (rp2){r.t0[2], r.t0[3]};
+    const rp2 p010 = (rp2){r.t1[0], r.t1[1]}, p011 = (rp2){r.t1[2], r.t1[3]};
+    const rp2 p100 = (rp2){r.t2[0], r.t2[1]}, p101 = (rp2){r.t2[2], r.t2[3]};
+    const rp2 p110 = (rp2){r.t3[0], r.t3[1]}, p111 = (rp2){r.t3[2], r.t3[3]};
+    const rp2 c00 = lerp_ref2(p000, p001, wk0, wk1), c01 = lerp_ref2(p010, p011, wk0, wk1);
+    const rp2 c10 = lerp_ref2(p100, p101, wk0, wk1), c11 = lerp_ref2(p110, p111, wk0, wk1);
+    const rp2 d0 = lerp_ref2(c00, c01, wj0[v], wj1[v]), d1 = lerp_ref2(c10, c11, wj0[v], wj1[v]);
+    const rp2 uv = lerp_ref2(d0, d1, wi0[v], wi1[v]);
+    const float uu = uv[0], vv = uv[1];
+    const int iu = (int)__fdiv_rn(uu, 2.f), iv = (int)__fdiv_rn(vv, 2.f);
+    if (a.idx_out) {
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      const int gi = w * VPT + v, il = gi % CI, jl = ((gi / CI) << 2) + (ln >> 4);
+      if (J0 + jl < G && K0 + (ln & 15) < G)
+        a.idx_out[((size_t)(t * C + c)) * nvox + ((size_t)(I0 + il) * G + (J0 + jl)) * G + K0 + (ln & 15)] =
+            iv * hs + iu;
+    }
+    const int hx = iu - 1 + a.heat_pad, hy = iv - 1 + a.heat_pad;
+    const int px = hx - g.x0, py = hy - g.y0;
+    int o = kZeroOff;                                                     // the (virtual) zero border
+    if (hx >= 0 && hy >= 0 && hx < Hh && hy < Hh) {
+      if (!g.big && px >= 0 && py >= 0 && px < g.pw && py < g.ph)
+        o = kPatchOff + (c & 1) * a.patch_bytes + (py * g.pwp + px) * (SPX * 16);
+      else
+        o = (int)0x80000000 | ((hy * Hh + hx) * JPB);
+    }
+    return o;
+  };
   auto tap_offsets = [&](int c, const Geo& g, int* off) __attribute__((always_inline)) {
-    const float2* cz = ctab + (c & 1) * NTAB;
 #pragma unroll
     for (int v = 0; v < VPT; ++v) {
-      // (u, v) pairs through packed fp32 instructions: half the vector instructions of the scalar form, the same
-      // IEEE operation per component (W (k) innermost, then H (j), then D (i))
-      const rp2* p = reinterpret_cast<const rp2*>(cz + cidx[v]);
-      const rp2 p000 = p[0], p001 = p[1];
-      const rp2 p010 = p[kTabK], p011 = p[kTabK + 1];
-      const rp2 p100 = p[kTabJ * kTabK], p101 = p[kTabJ * kTabK + 1];
-      const rp2 p110 = p[kTabJ * kTabK + kTabK], p111 = p[kTabJ * kTabK + kTabK + 1];
-      const rp2 c00 = lerp_ref2(p000, p001, wk0, wk1), c01 = lerp_ref2(p010, p011, wk0, wk1);
-      const rp2 c10 = lerp_ref2(p100, p101, wk0, wk1), c11 = lerp_ref2(p110, p111, wk0, wk1);
-      const rp2 d0 = lerp_ref2(c00, c01, wj0[v], wj1[v]), d1 = lerp_ref2(c10, c11, wj0[v], wj1[v]);
-      const rp2 uv = lerp_ref2(d0, d1, wi0[v], wi1[v]);
-      const float uu = uv[0], vv = uv[1];
-      const int iu = (int)__fdiv_rn(uu, 2.f), iv = (int)__fdiv_rn(vv, 2.f);
-      if (a.idx_out) {
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-        const int gi = w * VPT + v, il = gi % CI, jl = ((gi / CI) << 2) + (ln >> 4);
-        if (J0 + jl < G && K0 + (ln & 15) < G)
-          a.idx_out[((size_t)(t * C + c)) * nvox + ((size_t)(I0 + il) * G + (J0 + jl)) * G + K0 + (ln & 15)] =
-              iv * hs + iu;
-      }
-      const int hx = iu - 1 + a.heat_pad, hy = iv - 1 + a.heat_pad;
-      const int px = hx - g.x0, py = hy - g.y0;
-      int o = kZeroOff;                                                     // the (virtual) zero border
-      if (hx >= 0 && hy >= 0 && hx < Hh && hy < Hh) {
-        if (!g.big && px >= 0 && py >= 0 && px < g.pw && py < g.ph)
-          o = kPatchOff + (c & 1) * a.patch_bytes + (py * g.pwp + px) * (SPX * 16);
-        else
-          o = (int)0x80000000 | ((hy * Hh + hx) * JPB);
-      }
-      off[v] = o;
+      TapRaw r;
+      tap_request(c, v, r);
+      tap_wait(r);
+      off[v] = tap_finish(c, g, v, r);
     }
   };
   // patch of camera c -> LDS buffer c & 1.  LDS slot s (16 bytes) of a patch row = quad s % SPX of staged pixel
@@ -542,6 +601,15 @@ __global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
     if (2 < C && e * NT + tid < NTAB) tnext[e] = a.coarse[(size_t)(t * C + 2) * nvox_c + ctab_src[e]];
   }
   for (int c = 0; c < ((a.abl & 32) ? 1 : C); ++c) {
+    // (the table entry requested in the previous iteration is taken over BEFORE this iteration's DMA is issued: vector
+    //  memory operations return in order, and the number of DMA instructions is not a compile-time constant -- a wait for
+    //  the entry placed after them would be a wait for all of them)
+    float2 tv[TPT];
+#pragma unroll
+    for (int e = 0; e < TPT; ++e) {
+      tv[e] = tnext[e];
+      asm volatile("" : "+v"(tv[e].x), "+v"(tv[e].y));
+    }
     // camera c+1: box, patch in flight into the other buffer; camera c+2: table entry in flight
     Geo gn = gc;
     const bool more = c + 1 < C;
@@ -555,12 +623,9 @@ __global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
     // has two iterations to arrive.  (Requested and committed inside one iteration, its round trip was the floor under
     // every camera step: with patch loads, LDS gather and tap arithmetic ablated the kernel still took 0.57 ms, 0.35
     // without these loads.)
-    float2 tv[TPT];
 #pragma unroll
-    for (int e = 0; e < TPT; ++e) {
-      tv[e] = tnext[e];
+    for (int e = 0; e < TPT; ++e)
       if (c + 3 < C && e * NT + tid < NTAB && !(a.abl & 16)) tnext[e] = a.coarse[(size_t)(t * C + c + 3) * nvox_c + ctab_src[e]];
-    }
     // gather camera c: every lane reads the Q quads of its own voxels' pixels
     const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cam_base(cam_c)), 0,
                                                                            plane_bytes, 0x00020000);
@@ -569,8 +634,7 @@ __global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
     for (int v = 0; v < VPT; ++v) {
       const int o = off_c[v] >= 0 ? off_c[v] : kZeroOff;
       gf4 h[Q];
-#pragma unroll
-      for (int q = 0; q < Q; ++q) h[q] = *reinterpret_cast<const gf4*>(smem + o + q * 16);
+      lds_read_quads<Q>(h, lds0 + (unsigned)o);
 #pragma unroll
       for (int q = 0; q < Q; ++q) {
         acc[v][q][0] += __builtin_shufflevector(h[q], h[q], 0, 1);
@@ -594,9 +658,11 @@ __global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
         }
       }
     }
-    // (tried, round 5: half of the waves interpolating camera c+1's taps BEFORE they gather camera c, so that the
+    // (tried, round 5: (1) half of the waves interpolating camera c+1's taps BEFORE they gather camera c, so that the
     //  workgroup's waves do not hit the LDS pipe and then the vector ALU in lock step -- as a wave-uniform branch over two
-    //  copies of this body it takes the kernel from 116 to 128 registers with 50 spills)
+    //  copies of this body it takes the kernel from 116 to 128 registers with 50 spills; (2) per voxel, the table reads
+    //  of camera c+1 and the pixel reads of camera c under ONE wait: 128 registers with 10 spills at 24 channels, 0.81
+    //  against 0.68 ms; without spills, at 32 channels, 1.22 against 1.23 ms)
     if (more && !(a.abl & 4) && wave_in) tap_offsets(c + 1, gn, off_c);          // (reads table (c+1) & 1; off_c of camera c is spent)
     // table of camera c+2 over the table of camera c (read for the last time one iteration ago)
 #pragma unroll
@@ -604,6 +670,8 @@ __global__ __launch_bounds__(NT) void repro_cube_kernel(CubeArgs a) {
       if (c + 2 < C && e * NT + tid < NTAB) ctab[(c & 1) * NTAB + e * NT + tid] = tv[e];
     // one barrier per camera: patch c+1 has landed (vmcnt) and is visible, table c+2 is visible, and
     // nobody still reads patch c, whose buffer the next iteration's prefetch overwrites
+    // patch c+1 (this wave's rows of it) has landed: the DMA is waited for HERE, after the step's arithmetic
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (!(a.abl & 128)) __syncthreads();
     gc = gn;
     cam_c = cam_n;
