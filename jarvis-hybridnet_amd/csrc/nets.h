@@ -64,11 +64,20 @@ class Plan {
   int upload(const std::vector<float>& host, float** dev);
   int get(const ParamMap& pm, const std::string& key, size_t numel, const float** out);
 
-  struct Op { std::function<int(hipStream_t)> fn; std::string name; double flops, bytes; };
+  // lane 1: the op belongs to a SIDE BRANCH -- it depends on nothing the main lane launches between the branch's first
+  // op and the next op marked `join` (which, and everything behind it, may read what the branch wrote).  run() forks a
+  // second stream at the first op of a branch and joins it at the marked op: two independent chains of a latency-bound
+  // forward (single frame sets) then run side by side -- inside a captured hipGraph as two branches.
+  struct Op { std::function<int(hipStream_t)> fn; std::string name; double flops, bytes; int lane = 0; bool join = false; };
   std::vector<Op> ops_;
+  int lane_ = 0;                             // lane of the ops pushed from here on (builders set it around a branch)
+  bool join_next_ = false;                   // the next op pushed joins the side branch
   void push(const std::string& name, double flops, double bytes, std::function<int(hipStream_t)> fn) {
-    ops_.push_back(Op{std::move(fn), name, flops, bytes});
+    ops_.push_back(Op{std::move(fn), name, flops, bytes, lane_, join_next_});
+    join_next_ = false;
   }
+  hipStream_t side_ = nullptr;               // created by finish() when the plan has a side branch
+  hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
   std::vector<void*> owned_;
   std::vector<ConvWeights> convs_;
   double* arena_ = nullptr;

@@ -40,6 +40,9 @@ int Profiler::finish() {
 Plan::~Plan() {
   for (void* p : owned_) (void)hipFree(p);
   for (auto& c : convs_) free_conv_weights(&c);
+  if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+  if (ev_join_) (void)hipEventDestroy(ev_join_);
+  if (side_) (void)hipStreamDestroy(side_);
 }
 
 int Plan::alloc(void** p, size_t bytes) {
@@ -65,6 +68,13 @@ size_t Plan::scratch(size_t doubles) {
 
 int Plan::finish() {
   if (arena_doubles_ == 0) arena_doubles_ = 8;
+  bool branch = false;
+  for (const auto& op : ops_) branch = branch || op.lane != 0;
+  if (branch) {       // (created here, at build time: run() may be inside a stream capture)
+    JH_CHECK_HIP(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
+    JH_CHECK_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+    JH_CHECK_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+  }
   return alloc(reinterpret_cast<void**>(&arena_), arena_doubles_ * sizeof(double));
 }
 
@@ -79,11 +89,33 @@ void set_precision_mode(int m) { g_precision = m; }
 int Plan::run(hipStream_t s) {
   if (launch_zero(arena_, arena_doubles_ * sizeof(double), s)) return 1;
   Profiler& pf = profiler();
+  // (profiled passes time every kernel alone: no side branch then)
+  const bool fork = side_ != nullptr && !pf.on;
+  bool side_busy = false;
+  auto join = [&]() {
+    JH_CHECK_HIP(hipEventRecord(ev_join_, side_));
+    JH_CHECK_HIP(hipStreamWaitEvent(s, ev_join_, 0));
+    side_busy = false;
+    return 0;
+  };
   for (auto& op : ops_) {
-    if (pf.on) pf.begin(op.name, op.flops, op.bytes, s);
-    if (op.fn(s)) return 1;
-    if (pf.on) pf.end(s);
+    hipStream_t os = s;
+    if (fork) {
+      if (op.join && side_busy && join()) return 1;
+      if (op.lane != 0) {
+        if (!side_busy) {                    // the branch starts behind everything launched so far
+          JH_CHECK_HIP(hipEventRecord(ev_fork_, s));
+          JH_CHECK_HIP(hipStreamWaitEvent(side_, ev_fork_, 0));
+          side_busy = true;
+        }
+        os = side_;
+      }
+    }
+    if (pf.on) pf.begin(op.name, op.flops, op.bytes, os);
+    if (op.fn(os)) return 1;
+    if (pf.on) pf.end(os);
   }
+  if (side_busy && join()) return 1;
   return 0;
 }
 
@@ -663,7 +695,15 @@ int V2VPlan::build(const ParamMap& pm, const std::string& pre, int J, int T, int
   if (!lazy) add_norm(f0, st, ACT_RELU, nullptr, nullptr, f0.p, -1);
   if (res_block(pm, pre + "front_layers.1.", 2 * J, f0, nullptr, &f1, lazy ? (long)st : -1)) return 1;
   const std::string e = pre + "encoder_decoder.";
+  // skip_res1 (three launches) depends on f1 only and is read again by decoder_res1's closing pass, so it can run as a
+  // side branch next to encoder_pool1 .. decoder_upsample1 (Plan::run forks a second stream; statistics and activations
+  // of the two chains are disjoint).  Measured on the single-frame forward, where the V2V stage is a chain of 47-us
+  // launches: 2.089 ms with the branch against 2.059 without (medium 3.68 / 3.59) -- each of these kernels already
+  // spreads over the chip, the two chains only take turns.  Opt-in: JH_V2V_FORK=1.
+  const bool fork = T < 8 && JH_ENV_KNOB("JH_V2V_FORK") == 1;
+  if (fork) lane_ = 1;
   if (res_block(pm, e + "skip_res1.", 2 * J, f1, nullptr, &skip)) return 1;
+  lane_ = 0;
   if (new_act(T, Gq, Gq, Gq, 4 * J, &e0)) return 1;
   if (add_conv(pm, conv_desc(3, 2, 2, 0, 2 * J, 4 * J), e + "encoder_pool1.block.0.weight",
                e + "encoder_pool1.block.0.bias", false, f1, e0, nullptr, true, &st)) return 1;
@@ -673,6 +713,8 @@ int V2VPlan::build(const ParamMap& pm, const std::string& pre, int J, int T, int
   if (add_conv(pm, deconv3d_k2s2_desc(4 * J, 2 * J), e + "decoder_upsample1.block.0.weight",
                e + "decoder_upsample1.block.0.bias", true, e1, u0, nullptr, true, &st)) return 1;
   if (!lazy) add_norm(u0, st, ACT_RELU, nullptr, nullptr, u0.p, -1);
+  // (decoder_res1's first two launches do not read `skip`, its closing pass does: the join sits in front of the block)
+  if (fork) join_next_ = true;
   if (res_block(pm, e + "decoder_res1.", 2 * J, u0, skip.p, &d1, lazy ? (long)st : -1)) return 1;   // ... + res1
   if (new_act(T, Gh, Gh, Gh, J, &output)) return 1;
   if (add_conv(pm, conv_desc(3, 1, 1, 0, 2 * J, J), pre + "output_layer.weight",
