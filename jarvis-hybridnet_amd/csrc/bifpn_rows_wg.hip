@@ -308,6 +308,11 @@ static int launch_rows_wg_rc(const NodeArgs& a, hipStream_t s) {
   int seg_rows = JH_ENV_KNOB("JH_NODE_SEG") > 0 ? JH_ENV_KNOB("JH_NODE_SEG")
                  : a.rows == 2 ? (a.H >= 64 ? 16 : (a.H >= 32 ? 4 : 2))
                  : (a.n_in == 2 || a.mode[1] == FUSE_SAME ? std::max(8, a.H / 2) : (a.H >= 64 ? 16 : 8));
+  // (time-batch class >= 8, levels of 32 pixels and more: ONE segment per strip -- the workgroup's prologue (its waves'
+  //  weight slices, the statistics' fp64 arithmetic, two warm-up rows) is paid once per 64 rows instead of per 16 or 32:
+  //  measured at 160 channels, 384 images: P3 node 1.218 -> 1.133 ms, head 1.270 -> 1.024, P4 0.331 -> 0.292 / 0.431 ->
+  //  0.389; the 16-pixel levels keep 8 rows, 0.106 against 0.112 with 16)
+  if (a.rows != 2 && JH_ENV_KNOB("JH_NODE_SEG") <= 0 && a.H >= 32) seg_rows = a.H;
   seg_rows = (seg_rows + 1) & ~1;
   if (seg_rows > a.H) seg_rows = a.H;
   const int segs = (a.H + seg_rows - 1) / seg_rows;
