@@ -127,11 +127,30 @@ void free_conv_weights(ConvWeights* w) {
   w->w = w->bias = nullptr;
 }
 
-static int pick_nr(int nb) {
-  int best = 1, best_waste = 1 << 30;
+// Column blocks (of 16 output channels) per workgroup.  A workgroup stages its input operand once per GROUP of nr
+// column blocks (global loads, InstanceNorm / activation / SE gate on load, LDS writes) and every tap re-uses the staged
+// patch, so the cost of a layer is about groups x (stage + nr) in units of one column block's MFMAs, with
+// stage = 1.5 / taps for operands that take SiLU (two transcendentals per element) and an SE gate on load -- the project
+// convolutions of the MBConv blocks -- and 0.5 / taps otherwise: for those pointwise layers a padded last group is
+// cheaper than more groups, for the k x k layers the padding is what counts.  (Rounds 1-4 minimised the padding alone: 5
+// and 7 column blocks -- the 80- and 112-channel project convolutions of the medium model -- ran with nr = 1, i.e. staged
+// a 480- / 672-channel operand five / seven times: 0.266 -> 0.189 ms for 672 -> 112 at 384 images.)  nr only partitions
+// the output channels: outputs and statistics are the same bits for any nr.
+static int pick_nr(int nb, int taps, bool heavy_staging) {
+  if (JH_ENV_KNOB("JH_CONV_NR_RULE") == 0) {     // the old rule: least padding, larger nr first
+    int best = 1, best_waste = 1 << 30;
+    for (int nr = 4; nr >= 1; --nr) {
+      const int waste = (nb + nr - 1) / nr * nr - nb;
+      if (waste < best_waste) { best_waste = waste; best = nr; }
+    }
+    return best;
+  }
+  const double stage = (heavy_staging ? 1.5 : 0.5) / (double)taps;
+  int best = 1;
+  double best_cost = 1e30;
   for (int nr = 4; nr >= 1; --nr) {
-    const int waste = (nb + nr - 1) / nr * nr - nb;
-    if (waste < best_waste) { best_waste = waste; best = nr; }
+    const double cost = (double)((nb + nr - 1) / nr) * (stage + nr);
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = nr; }
   }
   return best;
 }
@@ -162,7 +181,8 @@ int launch_conv(const ConvDesc& d, const ConvWeights& w, const Act& x, const Act
   int Do, Ho, Wo;
   conv_out_shape(d, x.D, x.H, x.W, &Do, &Ho, &Wo);
   JH_REQUIRE(Do == y.D && Ho == y.H && Wo == y.W, "conv output extent mismatch");
-  const int nr = pick_nr(w.cout_p16 / 16);
+  const int taps = d.k * d.k * (d.nd == 3 ? d.k : 1);
+  const int nr = pick_nr(w.cout_p16 / 16, taps, (in && in->stats && in->act == ACT_SILU) || gate || (se && se->pool));
   // LDS budget of the staged channel chunk (pick_kc8): 40 KB -- three to four workgroups per CU for the k5 / k4T
   // layers -- measured against 72 KB (two): k5s2 16->96 308 -> 287 us, head ConvTranspose 954 -> 928 us
   const size_t budget = 40 * 1024;
