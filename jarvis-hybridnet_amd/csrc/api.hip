@@ -349,6 +349,9 @@ int jh_predictor_create(const jh_params* center_params, const jh_params* hybrid_
   const int N = pr->T * pr->Cloc;
   // (form of the BiFPN nodes: by the time batch alone, see EffTrackPlan::node_rows)
   const int node_rows = pr->T >= 8 ? 1 : 0;
+  // (... and with it the blocking of the InstanceNorm / pooled-sum passes, Plan::norm_block_kb; JH_NODE_ROWS=0 switches
+  //  every class-dependent form off: one arithmetic for all time batches)
+  const int norm_kb = node_rows && JH_ENV_KNOB("JH_NODE_ROWS") != 0 ? 64 : 0;
   // precision: the predictor's own setting; JH_PRECISION_DEFAULT follows the process-wide default
   JH_REQUIRE(cfg->precision >= JH_PRECISION_DEFAULT && cfg->precision <= JH_PRECISION_BF16X3_WIDE,
              "jh_predictor_config.precision: unknown mode");
@@ -358,15 +361,18 @@ int jh_predictor_create(const jh_params* center_params, const jh_params* hybrid_
     pr->center.reset(new EffTrackPlan());
     pr->center->precision = precision;
     pr->center->node_rows = node_rows;
+    pr->center->norm_block_kb = norm_kb;
     if (pr->center->build(center_params->map, "", cfg->center_model, 1, N, cfg->center_size,
                           cfg->center_size)) return 1;
   }
   pr->kp.reset(new EffTrackPlan());
   pr->kp->precision = precision;
   pr->kp->node_rows = node_rows;
+  pr->kp->norm_block_kb = norm_kb;
   if (pr->kp->build(hybrid_params->map, "effTrack.", cfg->kp_model, pr->J, N, pr->B, pr->B)) return 1;
   pr->v2v.reset(new V2VPlan());
   pr->v2v->precision = precision;
+  pr->v2v->norm_block_kb = norm_kb;
   if (pr->v2v->build(hybrid_params->map, "v2vNet.", pr->J, pr->T3, pr->G)) return 1;
   auto& m = pr->mem;
   const int T = pr->T, C = pr->C;

@@ -156,7 +156,8 @@ __global__ __launch_bounds__(1024) void norm_apply_kernel(
 }
 
 int launch_norm_apply(const Act& x, const double* stats, float eps, int act, const float* r1,
-                      const float* r2, float* y, double* pool, hipStream_t s, const double* r1_stats) {
+                      const float* r2, float* y, double* pool, hipStream_t s, const double* r1_stats,
+                      int min_block_kb) {
   const int P = (int)x.pixels();
   const int q = x.Cp / 4;
   JH_REQUIRE(q >= 1 && q <= 256, "channel count out of range for norm_apply");
@@ -170,6 +171,13 @@ int launch_norm_apply(const Act& x, const double* stats, float eps, int act, con
   // arithmetic and must not depend on the batch size.
   int iters = 8;
   while ((P + rows * iters - 1) / (rows * iters) > 64 && iters < 64) iters *= 2;
+  // ... and at least `min_block_kb` of the tensor per block (the caller's choice -- plans of the time-batch class >= 8
+  // ask for 64 KB; JH_NORM_MINKB overrides): a block's prologue turns the statistics of ALL its channels into mean / rstd
+  // with fp64 arithmetic; with 480 channels and 16 pixels per block that was most of its life (small/small kernel time
+  // 16.46 -> 16.31 ms per batch, medium 38.69 -> 38.19).  Single frame sets keep the small blocks: 12 images have to
+  // spread over 256 CUs (2.059 against 2.090 ms per forward).
+  const int min_kb = JH_ENV_KNOB("JH_NORM_MINKB") >= 0 ? JH_ENV_KNOB("JH_NORM_MINKB") : min_block_kb;
+  while ((long)rows * iters * x.Cp * 4 < (long)min_kb * 1024 && iters < 64 && rows * iters < P) iters *= 2;
   const int ppb = rows * iters;
   dim3 grid((P + ppb - 1) / ppb, x.N);
   const size_t sm = ((pool ? (size_t)rows * q * 4 : 0) + (stats ? (size_t)2 * x.Cp : 0)) * sizeof(float);

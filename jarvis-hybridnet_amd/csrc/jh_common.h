@@ -187,7 +187,7 @@ ConvDesc deconv3d_k2s2_desc(int cin, int cout);
 // r1_stats: r1 is a RAW tensor; its InstanceNorm + ReLU is applied on load (act must be ACT_RELU)
 int launch_norm_apply(const Act& x, const double* stats, float eps, int act,
                       const float* r1, const float* r2, float* y, double* pool,
-                      hipStream_t s, const double* r1_stats = nullptr);
+                      hipStream_t s, const double* r1_stats = nullptr, int min_block_kb = 0);
 // squeeze-excite gate from pooled sums: gate[n][c] = sigmoid(We silu(Wr mean + br) + be)
 int launch_se_gate(const double* pool, int N, int C, int Cp, int S, float inv_hw,
                    const float* wr, const float* br, const float* we, const float* be,

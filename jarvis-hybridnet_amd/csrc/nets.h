@@ -54,6 +54,10 @@ class Plan {
   // the process default (jh_set_precision / JH_PRECISION) at construction; an owner with its own setting
   // (jh_predictor_config::precision) overrides it before build().
   int precision = precision_mode();
+  // Least tensor bytes per workgroup of the InstanceNorm / pooled-sum passes (launch_norm_apply): part of the pooled
+  // sums' arithmetic, so -- like the BiFPN nodes' form -- a function of the predictor's time-batch class only (64 KB
+  // for time batches >= 8, 0 = small blocks for single frame sets); set before build().
+  int norm_block_kb = 0;
 
  protected:
   int alloc(void** p, size_t bytes);

@@ -224,7 +224,7 @@ void Plan::add_norm(const Act& x, size_t stats_off, int act, const float* r1, co
        [this, x, stats_off, act, r1, r2, y, pool_off, r1_stats_off](hipStream_t s) {
     return launch_norm_apply(x, sc(stats_off), 1e-5f, act, r1, r2, y,
                              pool_off >= 0 ? sc((size_t)pool_off) : nullptr, s,
-                             r1_stats_off >= 0 ? sc((size_t)r1_stats_off) : nullptr);
+                             r1_stats_off >= 0 ? sc((size_t)r1_stats_off) : nullptr, norm_block_kb);
   });
 }
 
