@@ -2,6 +2,7 @@
 #include <vector>
 #include <cstring>
 #include <cstdlib>
+#include <algorithm>
 #include "conv_mfma.h"
 
 namespace jh {
@@ -136,7 +137,7 @@ void free_conv_weights(ConvWeights* w) {
 // and 7 column blocks -- the 80- and 112-channel project convolutions of the medium model -- ran with nr = 1, i.e. staged
 // a 480- / 672-channel operand five / seven times: 0.266 -> 0.189 ms for 672 -> 112 at 384 images.)  nr only partitions
 // the output channels: outputs and statistics are the same bits for any nr.
-static int pick_nr(int nb, int taps, bool heavy_staging) {
+static int pick_nr(int nb, int taps, bool heavy_staging, long units) {
   if (JH_ENV_KNOB("JH_CONV_NR_RULE") == 0) {     // the old rule: least padding, larger nr first
     int best = 1, best_waste = 1 << 30;
     for (int nr = 4; nr >= 1; --nr) {
@@ -146,10 +147,16 @@ static int pick_nr(int nb, int taps, bool heavy_staging) {
     return best;
   }
   const double stage = (heavy_staging ? 1.5 : 0.5) / (double)taps;
+  // A launch of fewer workgroups than the chip holds (`units` = tiles x images: a single frame set has 24 tiles at the
+  // 16-pixel levels) is as slow as ONE workgroup: stage + nr, so the narrow groups win until the chip is full.  One
+  // frame set, us per launch: k5 s2 16 -> 96 28.8 -> 21.4, k3 40 -> 240 20.7 -> 15.7; single-frame latency small / small
+  // 2.06 -> 2.00 ms, medium 3.59 -> 3.40, large 6.29 -> 6.17.  JH_CONV_NR_FILL=0: off (the throughput rule alone).
+  const long slots = JH_ENV_KNOB("JH_CONV_NR_FILL") >= 0 ? std::max(1, JH_ENV_KNOB("JH_CONV_NR_FILL")) : 512;
   int best = 1;
   double best_cost = 1e30;
   for (int nr = 4; nr >= 1; --nr) {
-    const double cost = (double)((nb + nr - 1) / nr) * (stage + nr);
+    const long groups = (nb + nr - 1) / nr;
+    const double cost = (double)std::max(units * groups, slots) * (stage + nr);
     if (cost < best_cost - 1e-9) { best_cost = cost; best = nr; }
   }
   return best;
@@ -182,7 +189,12 @@ int launch_conv(const ConvDesc& d, const ConvWeights& w, const Act& x, const Act
   conv_out_shape(d, x.D, x.H, x.W, &Do, &Ho, &Wo);
   JH_REQUIRE(Do == y.D && Ho == y.H && Wo == y.W, "conv output extent mismatch");
   const int taps = d.k * d.k * (d.nd == 3 ? d.k : 1);
-  const int nr = pick_nr(w.cout_p16 / 16, taps, (in && in->stats && in->act == ACT_SILU) || gate || (se && se->pool));
+  long units;                                   // tiles x images of the launch (the default tile of each family)
+  if (d.nd == 2) units = (long)((a.Hout + 7) / 8) * ((a.Wout <= 8 ? a.Wout + 7 : a.Wout + 15) / (a.Wout <= 8 ? 8 : 16));
+  else units = (long)((a.Dout + 1) / 2) * ((a.Hout + 3) / 4) * ((a.Wout + 15) / 16);
+  units *= (long)a.nphase * a.N;
+  const int nr = pick_nr(w.cout_p16 / 16, taps, (in && in->stats && in->act == ACT_SILU) || gate || (se && se->pool),
+                         units);
   // LDS budget of the staged channel chunk (pick_kc8): 40 KB -- three to four workgroups per CU for the k5 / k4T
   // layers -- measured against 72 KB (two): k5s2 16->96 308 -> 287 us, head ConvTranspose 954 -> 928 us
   const size_t budget = 40 * 1024;
