@@ -15,7 +15,8 @@ c = cases.PREDICTOR_CASES[CASE]
 inp = cases.predictor_inputs(CASE)
 T, REPS, STREAMS = int(os.environ.get("T", "32")), int(os.environ.get("REPS", "20")), 3
 kw = dict(num_cameras=c["C"], num_joints=c["J"], center_size=c["center_size"], bbox=c["bbox"],
-          roi_cube_size=c["roi"], grid_spacing=c["spacing"], img_h=c["H"], img_w=c["W"], mean=S.MEAN, std=S.STD)
+          roi_cube_size=c["roi"], grid_spacing=c["spacing"], img_h=c["H"], img_w=c["W"], mean=S.MEAN, std=S.STD,
+          center_model=c.get("size", "small"), kp_model=c.get("size", "small"))
 dev = [t.cuda() for t in (inp["cam"], inp["intr"], inp["dist"])]
 one = inp["imgs"].cuda().unsqueeze(0).contiguous()
 p1 = NativePredictor(inp["sd_center"], inp["sd_hybrid"], time_batch=1, **kw)
