@@ -832,7 +832,7 @@ int jh_op_conv(int nd, int kind, int k, int stride, int pad, int cin, int cout,
     else if (b3) { if ((rc = launch_conv3d_bf16x3(cw, x, y, stats, s, nullptr))) break; }
     else if (wino) { if ((rc = launch_conv3d_wino(cw, x, y, stats, s, nullptr, wino_variant_from_env()))) break; }
     else if ((rc = launch_conv(desc, cw, x, y, gate_p, stats, s))) break;
-    if (norm_act >= 0 && (rc = launch_norm_apply(y, stats, 1e-5f, norm_act, nullptr, nullptr, y.p, nullptr, s))) break;
+    if (norm_act >= 0 && (rc = launch_norm_apply(y, stats, 1e-5, norm_act, nullptr, nullptr, y.p, nullptr, s))) break;
     if ((rc = launch_from_channel_last(y, y_dev, s))) break;
     if (hipStreamSynchronize(s) != hipSuccess) { set_error("stream sync failed in jh_op_conv"); rc = 1; }
   } while (0);
@@ -859,7 +859,7 @@ int jh_op_depthwise(int k, int c, const float* w_host, const float* x_dev, int n
   }
   if (launch_to_channel_last(x_dev, x, s)) return 1;
   if (launch_depthwise(x, wd, k, y.p, stats, s)) return 1;
-  if (norm_act >= 0 && launch_norm_apply(y, stats, 1e-5f, norm_act, nullptr, nullptr, y.p, nullptr, s)) return 1;
+  if (norm_act >= 0 && launch_norm_apply(y, stats, 1e-5, norm_act, nullptr, nullptr, y.p, nullptr, s)) return 1;
   if (launch_from_channel_last(y, y_dev, s)) return 1;
   JH_CHECK_HIP(hipStreamSynchronize(s));
   return 0;

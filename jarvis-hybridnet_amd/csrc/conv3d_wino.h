@@ -48,7 +48,6 @@ inline WinoTiling wino_tiling(int D, int H, int W, int tz) {
 }
 inline int wino_blocks_per_slab(const WinoTiling& g) { return g.n44x * g.n44y + g.nR + g.nB; }
 
-struct WinoTileEntry;
 struct WinoArgs {
   const float* x;          // [N][D][H][W][cin_p]
   float* y;                // [N][D][H][W][cout_p] raw output
@@ -62,8 +61,7 @@ struct WinoArgs {
   int abl;                 // experiment knob (JH_WS_ABL), 0 in production
   long long* dbg;          // per-phase cycle sums of workgroup 0 (JH_WINO_DBG), nullptr in production
   WinoTiling tiling;       // block shapes of a z-slice (filled by launch_conv3d_wino)
-  const WinoTileEntry* tiles;   // tiling.shaped: the N * slabs * blocks-per-slab tiles of a column-block group (device)
-  const int* shape_tab;         // ... and the loader's per-shape patch tables, [3][kWinoShapeWords] (device)
+  const int* shape_tab;    // tiling.shaped: the loader's per-shape patch tables, [3][kWinoShapeWords] (device)
 };
 
 struct WinoTile { int n, z0, y0, x0, lc, hlim, wlim; };    // hlim / wlim: outputs of this block at y >= hlim or x >= wlim
@@ -98,20 +96,16 @@ inline WinoTile wino_decode(const WinoTiling& g, int N, int H, int W, int tz, in
   }
   return t;
 }
-// The persistent kernel reads its tiles from a table (one 8-byte entry per tile of a column-block group, built on the
-// host with wino_decode: the five integer divisions of the decode, on scalar registers the kernel does not have to
-// spare, become one load): x = n | z0 << 16, y = x0 | y0 << 12 | lc << 24.
-struct WinoTileEntry { int x, y; };
-inline WinoTileEntry wino_pack_tile(const WinoTile& t) { return {t.n | (t.z0 << 16), t.x0 | (t.y0 << 12) | (t.lc << 24)}; }
-
-// ... and the loader wave's per-lane patch tables, one set per block shape (index lc - 1), from a table too: 21 rounds
+// Both kernels decode their tiles arithmetically (a per-tile table LOAD cost an lgkmcnt(0) wait at every tile boundary of
+// every wave: 0.65 vs 0.57 ms).  The persistent kernel's loader wave takes its per-lane patch tables, one set per block
+// shape (index lc - 1), from a table: 21 rounds
 // of 64 float4 items cover the 6 x 108 x 2 items of the largest patch; words [k][lane], k < 21: byte offset of item
 // (lane + 64 k) relative to the patch origin, k = 21 .. 27: the lane's item masks z0, z1, y0, y1, x0, x1 (first / beyond-
 // last patch plane of the volume's first / last block along that axis) and `tail` (items beyond the patch).
 constexpr int kWinoShapeIter = 21, kWinoShapeWords = (kWinoShapeIter + 7) * 64;
-// host: [3 shapes][kWinoShapeWords] ints, then the WinoTileEntry list of a launch over N images of D x H x W with cin_p
-// input channels (empty when the volume has no remainder strips)
-std::vector<int> wino_tables(int N, int D, int H, int W, int cin_p);
+// host: [3 shapes][kWinoShapeWords] ints for a D x H x W volume with cin_p input channels (empty when the volume has no
+// remainder strips)
+std::vector<int> wino_tables(int D, int H, int W, int cin_p);
 
 // persistent form; returns -1 when the launch should fall back to the one-role kernel
 int launch_conv3d_wino_pw(const WinoArgs& a, int nr, hipStream_t s);

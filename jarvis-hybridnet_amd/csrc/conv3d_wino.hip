@@ -391,9 +391,10 @@ int wino_variant_from_env() {
   return 4;
 }
 
-// Host side of the persistent kernel's tables (conv3d_wino.h): the loader's per-shape patch tables, then the tiles of
-// one column-block group in the kernel's linear order.  Empty for volumes without remainder strips.
-std::vector<int> wino_tables(int N, int D, int H, int W, int cin_p) {
+// Host side of the persistent kernel's tables (conv3d_wino.h): the loader's per-shape patch tables (the tiles themselves
+// are decoded arithmetically by the kernel).  A function of the volume and the channel padding only -- not of the
+// batch.  Empty for volumes without remainder strips.
+std::vector<int> wino_tables(int D, int H, int W, int cin_p) {
   const WinoTiling g = wino_tiling(D, H, W, 4);
   std::vector<int> t;
   if (!g.shaped) return t;
@@ -418,12 +419,6 @@ std::vector<int> wino_tables(int N, int D, int H, int W, int cin_p) {
       for (int k = 0; k < 7; ++k) tab[(kWinoShapeIter + k) * 64 + lane] = (int)m[k];
     }
   }
-  const int n = N * g.slabs * wino_blocks_per_slab(g);
-  for (int r = 0; r < n; ++r) {
-    const WinoTileEntry e = wino_pack_tile(wino_decode(g, N, H, W, 4, r));
-    t.push_back(e.x);
-    t.push_back(e.y);
-  }
   return t;
 }
 
@@ -444,20 +439,22 @@ int launch_conv3d_wino(const ConvWeights& w, const Act& x, const Act& y, double*
   a.tiling = wino_tiling(x.D, x.H, x.W, tz);
   const bool sh = a.tiling.shaped != 0;
   if (sh && variant == 4 && !tables) {
-    // callers outside a network plan (the op-level test entry): one table per launch shape, built on first use and kept
+    // callers outside a network plan (the op-level test entry only; plans pass their own tables, so this allocation
+    // never runs under stream capture): one 5 KB table per (device, volume, channel padding), built on first use
     static std::mutex mu;
     static std::map<std::array<int, 5>, int*> cache;
     std::lock_guard<std::mutex> lock(mu);
-    int*& dev = cache[{x.N, x.D, x.H, x.W, x.Cp}];
+    int device = 0;
+    JH_CHECK_HIP(hipGetDevice(&device));
+    int*& dev = cache[{device, x.D, x.H, x.W, x.Cp}];
     if (!dev) {
-      const std::vector<int> host = wino_tables(x.N, x.D, x.H, x.W, x.Cp);
+      const std::vector<int> host = wino_tables(x.D, x.H, x.W, x.Cp);
       JH_CHECK_HIP(hipMalloc(&dev, host.size() * sizeof(int)));
       JH_CHECK_HIP(hipMemcpy(dev, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice));
     }
     tables = dev;
   }
   a.shape_tab = tables;
-  a.tiles = tables ? reinterpret_cast<const WinoTileEntry*>(tables + 3 * kWinoShapeWords) : nullptr;
   if (variant == 4) {
     const int rc = launch_conv3d_wino_pw(a, nr_full, s);
     if (rc >= 0) return rc;                 // -1: too few tiles / one channel pass -> one-role kernel

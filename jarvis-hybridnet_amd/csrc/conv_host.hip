@@ -220,8 +220,12 @@ int launch_conv(const ConvDesc& d, const ConvWeights& w, const Act& x, const Act
     // The choice depends on the IMAGE only, never on the batch size: fused statistics are sums of
     // per-workgroup fp32 partials, so the tiling is part of the arithmetic, and a frame must give
     // the same bits alone and inside any time batch (tests: test_forward_is_bitwise_reproducible).
+    // (`nr` above depends on the launch size, hence on the batch: the tile FORM is decided with the column-block
+    // grouping of the throughput rule alone -- units = "a full chip" -- which is a function of the layer only)
+    const int nr_form = pick_nr(w.cout_p16 / 16, taps,
+                                (in && in->stats && in->act == ACT_SILU) || gate || (se && se->pool), 1L << 40);
     const long tiles_big = (long)((a.Dout + 1) / 2) * ((a.Hout + 3) / 4) * ((a.Wout + 15) / 16) *
-                           a.nphase * ((w.cout_p16 / 16 + nr - 1) / nr);
+                           a.nphase * ((w.cout_p16 / 16 + nr_form - 1) / nr_form);
     int small = tiles_big < 16 ? 1 : 0;
     // 256-voxel tiles (4 row blocks per wave: half the weight traffic per MFMA, 2.5x
     // instead of 3.4x halo) for volumes of at least 32^3 outputs

@@ -56,7 +56,7 @@ __device__ __forceinline__ void block_channel_reduce(float4 s1, float4 s2, int n
 // tensor has 132 quads: one pixel row per 256 threads used 132 of them).
 template <int ACT, bool R1, bool R2, bool Y, bool R1N = false>
 __global__ __launch_bounds__(1024) void norm_apply_kernel(
-    const float* __restrict__ x, const double* __restrict__ stats, float eps,
+    const float* __restrict__ x, const double* __restrict__ stats, double eps,
     const float* __restrict__ r1, const float* __restrict__ r2, float* __restrict__ y,
     double* __restrict__ pool, int P, int Cp, int ppb, const double* __restrict__ stats1 = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(1024) void norm_apply_kernel(
       double var = exact_read(st + kLimbs) / (double)P - mu * mu;
       if (var < 0.0) var = 0.0;
       mr[c] = (float)mu;
-      mr[Cp + c] = (float)(1.0 / sqrt(var + (double)eps));
+      mr[Cp + c] = (float)(1.0 / sqrt(var + eps));
     }
     __syncthreads();
     if (active) {
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(1024) void norm_apply_kernel(
       double var = exact_read(st + kLimbs) / (double)P - mu * mu;
       if (var < 0.0) var = 0.0;
       mr[c] = (float)mu;
-      mr[Cp + c] = (float)(1.0 / sqrt(var + (double)eps));
+      mr[Cp + c] = (float)(1.0 / sqrt(var + eps));
     }
     __syncthreads();
     if (active) {
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(1024) void norm_apply_kernel(
     block_channel_reduce(ps, ps, 1, q, rows, tid, active, pool + (size_t)n * Cp * kLimbs, 1, sm);
 }
 
-int launch_norm_apply(const Act& x, const double* stats, float eps, int act, const float* r1,
+int launch_norm_apply(const Act& x, const double* stats, double eps, int act, const float* r1,
                       const float* r2, float* y, double* pool, hipStream_t s, const double* r1_stats,
                       int min_block_kb) {
   const int P = (int)x.pixels();

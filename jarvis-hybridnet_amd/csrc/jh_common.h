@@ -185,7 +185,7 @@ ConvDesc deconv3d_k2s2_desc(int cin, int cout);
 // y = act((x - mean) * rstd + r1) + r2  with per-(n,c) statistics from `stats`
 // (biased variance, eps); optional pooled sum of y per (n,c) into `pool`.
 // r1_stats: r1 is a RAW tensor; its InstanceNorm + ReLU is applied on load (act must be ACT_RELU)
-int launch_norm_apply(const Act& x, const double* stats, float eps, int act,
+int launch_norm_apply(const Act& x, const double* stats, double eps, int act,
                       const float* r1, const float* r2, float* y, double* pool,
                       hipStream_t s, const double* r1_stats = nullptr, int min_block_kb = 0);
 // squeeze-excite gate from pooled sums: gate[n][c] = sigmoid(We silu(Wr mean + br) + be)

@@ -189,7 +189,7 @@ int Plan::add_conv(const ParamMap& pm, const ConvDesc& d, const std::string& wke
   // tile table, built and uploaded here, at plan-build time (csrc/conv3d_wino.h)
   const int* wino_tiles = nullptr;
   if (wino && !b3) {
-    const std::vector<int> tt = wino_tables(y.N, y.D, y.H, y.W, x.Cp);
+    const std::vector<int> tt = wino_tables(y.D, y.H, y.W, x.Cp);
     if (!tt.empty()) {
       void* dev = nullptr;
       if (alloc(&dev, tt.size() * sizeof(int))) return 1;
@@ -222,7 +222,7 @@ void Plan::add_norm(const Act& x, size_t stats_off, int act, const float* r1, co
   // (bytes: one read of x and of each residual operand, one write of y -- none for the pooled-sums-only form)
   push("norm_apply", 8.0 * el, 4.0 * el * (1 + (y ? 1 : 0) + (r1 ? 1 : 0) + (r2 ? 1 : 0)),
        [this, x, stats_off, act, r1, r2, y, pool_off, r1_stats_off](hipStream_t s) {
-    return launch_norm_apply(x, sc(stats_off), 1e-5f, act, r1, r2, y,
+    return launch_norm_apply(x, sc(stats_off), 1e-5, act, r1, r2, y,
                              pool_off >= 0 ? sc((size_t)pool_off) : nullptr, s,
                              r1_stats_off >= 0 ? sc((size_t)r1_stats_off) : nullptr, norm_block_kb);
   });

@@ -114,6 +114,7 @@ class ShardedPredictor:
         self.cuda = torch.device(device).type == "cuda"
         self.s3d = torch.cuda.Stream(device=device) if self.cuda else None
         self._done3d = None                      # event: stage 3 of the last finished batch has read heat_recv
+        self._exchanged = None                   # event: the exchange in flight has completed (read its send buffer)
         self.trace = None                        # list of (label, timing event) while a timeline is being recorded
 
     def _mark(self, label):

@@ -56,6 +56,13 @@ class HybridNetBackbone(NativeModule):
         calibration (b,C,...) (entry 0 is used, as in the reference, repro_layer.py:113-117)
         -> (heatmap_final (b,J,Gh,Gh,Gh), heatmaps_padded (b,C,J,hs,hs),
             points3D (b,J,3), confidences (b,J))."""
+        for name, cls in (("effTrack", EfficientTrackBackbone), ("v2vNet", V2VNet)):
+            if not isinstance(getattr(self, name, None), cls):
+                # the reference's trt_mode seam assigns compiled callables here (jarvis3D.py:65-69): this forward is one
+                # native launch plan built from the modules' weights, a foreign callable would be silently ignored
+                raise RuntimeError("HybridNetBackbone.%s has been replaced by a %s; the native forward only runs its own "
+                                   "%s (load weights with load_state_dict())"
+                                   % (name, type(getattr(self, name, None)).__name__, cls.__name__))
         x = N.dev(imgs)
         pr = self._predictor(x.shape[0], x.shape[3])
         pr.set_calibration(cameraMatrices[0], intrinsicMatrices[0], distortionCoefficients[0])

@@ -80,9 +80,11 @@ def predict3D_frames(predictor, frame_sets, cameraMatrices, intrinsicMatrices,
 
     time_batch > 1 groups that many consecutive frame sets into one launch sequence
     (the throughput form the bench measures); rows are written in frame
-    order and are the same as with time_batch = 1 -- bit for bit up to time_batch 7, to about
-    1e-5 mm from 8 on (the high-resolution BiFPN nodes then run in their row-streaming form,
-    DESIGN.md section 1; a row does not depend on its position in the group or on `streams`).
+    order and are the same as with time_batch = 1 -- bit for bit up to time_batch 7; from 8 on (the class in which
+    the high-resolution BiFPN nodes run in their row-streaming form and the InstanceNorm / pooled-sum passes take
+    >= 64 KB blocks) to 2-6e-5 mm for the small and medium models and 1.8e-4 mm for the large
+    one (measured; tests/test_hip_predictor.py::test_predictor3d_time_batch_8_vs_fixture holds 3e-4).  A row does
+    not depend on its position in the group, on the group size inside a class, or on `streams`.
     A short last group is padded with its last frame set and the padding rows are dropped.
     streams > 1 keeps that many groups in flight on as many HIP streams (host frame sets and frame sets already
     resident in HBM alike); rows still come out in frame order and are identical to the streams = 1 run.

@@ -391,7 +391,7 @@ def reprojection_indices(grid, cam_m, intr, dist, center_hm, hs, G):
 
 def reprojection_forward(heatmaps_padded, center3d, center_hm, cam_m, intr,
                          dist, roi_cube_size, grid_spacing, chunk=None,
-                         return_idx=False):
+                         return_idx=False, idx_override=None):
     """ReprojectionLayer.forward, hybridnet/repro_layer.py:88-119.
 
     heatmaps_padded (1,C,J,hs,hs); center3d (1,3); center_hm (1,C,2);
@@ -399,13 +399,18 @@ def reprojection_forward(heatmaps_padded, center3d, center_hm, cam_m, intr,
     The reference materialises the (J, C*G^3) gather; `chunk` lets the oracle
     do it per joint range with identical arithmetic (mean over the camera
     axis of the same gathered values) to bound memory.
+    `idx_override` (C,G,G,G) int64 replaces the index field of
+    repro_layer.py:82-83 (checker use: see `tail_with_indices`).
     """
     hm = heatmaps_padded[0].transpose(0, 1)  # (J,C,hs,hs)
     J, C, hs = hm.shape[0], hm.shape[1], hm.shape[2]
     G = int(roi_cube_size / grid_spacing)
     grid = reprojection_grid(roi_cube_size, grid_spacing) + center3d[0]
-    idx, _, _ = reprojection_indices(grid, cam_m[0], intr[0], dist[0],
-                                     center_hm[0], hs, G)
+    if idx_override is None:
+        idx, _, _ = reprojection_indices(grid, cam_m[0], intr[0], dist[0],
+                                         center_hm[0], hs, G)
+    else:
+        idx = idx_override.long()
     off = torch.arange(0, hs * hs * C, hs * hs)
     flat_idx = (idx.flatten(1).transpose(1, 0) + off).transpose(1, 0).flatten()
     flat_hm = hm.flatten(1)
@@ -462,6 +467,78 @@ def hybridnet_forward(sd, model_size, roi_cube_size, grid_spacing, imgs,
     final, pts, conf = softargmax_tail(out, center3d, roi_cube_size,
                                        grid_spacing)
     return final, hm_pad, pts, conf
+
+
+def tail_with_indices(sd, heatmaps_padded, idx, center3d, roi_cube_size,
+                      grid_spacing, chunk=None):
+    """hybridnet/model.py:67-88 from the gather on, with the gather index field
+    GIVEN instead of computed (repro_layer.py:88-107 unchanged).
+
+    Checker use only.  torch's CPU kernels differ in the last bit between CPU
+    models, so the reference's OWN index field (repro_layer.py:82-83: a
+    truncation of u/2, v/2) differs in a handful of voxels between hosts --
+    wherever u/2 or v/2 lies within an ulp of an integer.  The HIP path's
+    indices are proven equal to the fixture host's (tests/test_hip_stages.py::
+    test_reprojection); feeding them here removes that host dependence, so the
+    comparison against an oracle run on ANY host can hold the strict bar.
+    heatmaps_padded (1,C,J,hs,hs), idx (C,G,G,G), center3d (1,3) int."""
+    vol = reprojection_forward(heatmaps_padded, center3d, None, None, None,
+                               None, roi_cube_size, grid_spacing, chunk=chunk,
+                               idx_override=idx)
+    out = v2v_forward(sd, vol / 255., "v2vNet.")
+    _, pts, conf = softargmax_tail(out, center3d, roi_cube_size, grid_spacing)
+    return pts, conf
+
+
+def index_flip_report(idx_a, idx_b, u, v, hs):
+    """Which voxels two index fields (C,G,G,G) disagree on, and how close this
+    host's u/2 resp. v/2 (fine coordinate fields of `reprojection_indices`)
+    is to an integer there: a flip caused by last-bit differences of the
+    floating-point path sits within a few ulp of a truncation boundary."""
+    bad = (idx_a != idx_b).nonzero()
+    rows = []
+    for c, i, j, k in bad.tolist():
+        hu, hv = float(u[c, i, j, k]) / 2, float(v[c, i, j, k]) / 2
+        du, dv = abs(hu - round(hu)), abs(hv - round(hv))
+        a, b = int(idx_a[c, i, j, k]), int(idx_b[c, i, j, k])
+        moved_u = (a % hs) != (b % hs)
+        moved_v = (a // hs) != (b // hs)
+        # the distance that matters: of the coordinate(s) whose truncation differs
+        d = max(du if moved_u else 0.0, dv if moved_v else 0.0)
+        # one ulp of the halved coordinate (float32)
+        ulp = 2.0 ** (math.floor(math.log2(max(abs(hu if moved_u else hv), 1e-30))) - 23)
+        rows.append(dict(voxel=[c, i, j, k], half_u=hu, half_v=hv,
+                         dist_to_integer=d, ulp=ulp, dist_in_ulp=d / ulp))
+    return rows
+
+
+def host_parity(sd_hybrid, inter, idx_hip, pts_hip, pts_host, calib, roi_cube_size,
+                grid_spacing, bbox, chunk=None):
+    """The HIP path's 3D keypoints against the oracle RUN ON THIS HOST, free of the host's
+    index flips: `inter` = the intermediates of `predictor3d_forward` on the same frame set,
+    `idx_hip` (C,G,G,G) the HIP path's gather indices for the oracle's own heat maps and centres,
+    `pts_host` the oracle's unmodified result.  Returns the raw distance, the number of index
+    flips, where they sit relative to the truncation boundary, and the distance to the oracle
+    re-run from the gather on with the HIP indices (the figure held to the 1e-3 mm bar)."""
+    cam, intr, dist = calib
+    G = int(roi_cube_size / grid_spacing)
+    hs = bbox // 2 + 2
+    c3i = inter["center3d"].int()[None]
+    grid = reprojection_grid(roi_cube_size, grid_spacing) + c3i[0]
+    ridx, u, v = reprojection_indices(grid, cam, intr, dist, inter["center_hm"], hs, G)
+    idx_hip = idx_hip.reshape(ridx.shape).long()
+    flips = int((idx_hip != ridx).sum())
+    out = dict(raw_mm=(pts_hip - pts_host).abs().max().item(), flips=flips, of=int(ridx.numel()))
+    if flips == 0:
+        out["same_indices_mm"] = out["raw_mm"]
+        out["flip_voxels"] = []
+        return out
+    with torch.no_grad():
+        pts_same, _ = tail_with_indices(sd_hybrid, inter["heatmaps_padded"], idx_hip, c3i,
+                                        roi_cube_size, grid_spacing, chunk=chunk)
+    out["same_indices_mm"] = (pts_hip - pts_same).abs().max().item()
+    out["flip_voxels"] = index_flip_report(idx_hip, ridx, u, v, hs)[:32]
+    return out
 
 
 # --------------------------------------------------------------------------

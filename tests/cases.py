@@ -41,6 +41,9 @@ REPRO_CASES = {
     # fall outside the crop (the asymmetric index clamp decides them).  make_golden asserts the clamp counts.
     "cfg2_edge": (4, 23, 48, 2, 256, 640, 512, 6000.0, 29),
     "cfg3_edge": (12, 23, 64, 2, 256, 1280, 1024, 9000.0, 29),
+    # the reference's DEFAULT crop (config/config.py:51: KEYPOINTDETECT.BOUNDING_BOX_SIZE = 320 => heat maps 160^2,
+    # hs = 162) on the shipped 72^3 grid
+    "def320": (12, 23, 72, 2, 320, 1280, 1024, 1800.0, 16),
 }
 
 # tag -> (J, G, weight seed, input seed)
@@ -125,6 +128,24 @@ PREDICTOR_CASES = {
                       W=1280, H=1024, focal=9000.0, cseed=50, hseed=51, fseed=52, clamps=(2, 2, 0, 2)),
     "cfg3_edge_b": dict(C=12, J=23, roi=128, spacing=2, bbox=256, center_size=256,
                         W=1280, H=1024, focal=10800.0, cseed=50, hseed=51, fseed=78, clamps=(3, 3, 10, 0)),
+    # --- the reference's DEFAULT configuration (config/config.py:36-37,49-51: medium / medium,
+    # CENTERDETECT.IMAGE_SIZE 320, KEYPOINTDETECT.BOUNDING_BOX_SIZE 320) on the shipped rig and grid
+    # (projects/Example_Project/config.yaml:36-37: 12 cameras, ROI 144 / spacing 2 => 72^3): P3 = 80^2, hs = 162 ---
+    "default_medium_320": dict(C=12, J=23, roi=144, spacing=2, bbox=320, center_size=320,
+                               W=1280, H=1024, focal=1800.0, cseed=66, hseed=63, fseed=52, size="medium"),
+    # --- sensor failures inside an otherwise valid 12-camera set (jarvis3D.py:143-157): camera 5 delivers an
+    # all-zero (dropout) resp. all-one (saturated) frame.  A constant frame has zero variance everywhere except at
+    # the zero padding of the stem, so its InstanceNorm statistics are the padding's; whether that camera passes the
+    # `> 50` gate is whatever the reference says (n_detect is recorded in predictor_meta.json: with these random-init
+    # weights it does, its false detection drags center3D 150-500 mm away and the crop clamps engage).  The saturated
+    # The triangulation with a false detection is ill-conditioned: the reference's float32 SVD is up to 0.13 mm / 1 px
+    # from the exact least-squares centre there (make_golden records `svd_noise_*` and asserts that the integer
+    # margins of center3D.int() / centerHMs clear twice that).  Cameras 10 (black) and 7 (white) give such margins;
+    # camera 5 leaves center3D 0.0025 mm (white) resp. a crop centre 0.03 px (black, noise 0.13 px) from an integer ---
+    "cfg3_cam_black": dict(C=12, J=23, roi=128, spacing=2, bbox=256, center_size=256,
+                           W=1280, H=1024, focal=1800.0, cseed=50, hseed=51, fseed=52, dead_cam=(10, 0.0)),
+    "cfg3_cam_white": dict(C=12, J=23, roi=128, spacing=2, bbox=256, center_size=256,
+                           W=1280, H=1024, focal=1800.0, cseed=50, hseed=51, fseed=52, dead_cam=(7, 1.0)),
 }
 
 
@@ -193,6 +214,8 @@ def predictor_inputs(tag):
     sd_c = S.efficienttrack_weights(size, 1, c["cseed"], deconv_std=std)
     sd_h = S.hybridnet_weights(size, c["J"], c["hseed"])
     imgs, joints, centre = S.blob_frames(calib, c["W"], c["H"], c["J"], c["fseed"])
+    if "dead_cam" in c:
+        imgs[c["dead_cam"][0]] = c["dead_cam"][1]
     out = dict(sd_center=sd_c, sd_hybrid=sd_h, imgs=imgs, cam=calib[0],
                intr=calib[1], dist=calib[2], joints=joints, centre=centre)
     if c.get("u8"):
@@ -239,3 +262,26 @@ def analysis_samples(num_joints=23, n=5, cams=2):
         preds.append(None if i == 2 else
                      (torch.rand((1, num_joints, 3), generator=g) * 200 - 100).float())
     return samples, preds
+
+
+# analyze_frames with the real predictor (SURVEY 8f rank 4 on the GPU): frame sets of the cfg2_partial case (weights
+# scaled so the per-camera centre maxima straddle the `> 50` gate).  Seed 53 = the fixture frame set (2 of 4 cameras
+# detect); 63 has ONE camera above 50 (maxima 39.0 / 53.2 / 38.1 / 45.8) -> (None, None) -> left out of the files.
+ANALYSIS_GPU_SEEDS = (53, 62, 63, 67, 69)
+ANALYSIS_GPU_VALID = (1, 1, 0, 1, 1)
+
+
+def analysis_gpu_samples():
+    """Dataset3D(analysisMode=True)-shaped samples (dataset3D.py:248-258: full frames as float64 (C,H,W,3) RGB in
+    [0,1], ground-truth keypoints, ..., dataset name, file name) around the cfg2_partial predictor inputs."""
+    c = PREDICTOR_CASES["cfg2_partial"]
+    inp = predictor_inputs("cfg2_partial")
+    calib = (inp["cam"], inp["intr"], inp["dist"])
+    samples, frames = [], []
+    for i, seed in enumerate(ANALYSIS_GPU_SEEDS):
+        imgs, joints, _ = S.blob_frames(calib, c["W"], c["H"], c["J"], seed)
+        frames.append(imgs)
+        samples.append([imgs.permute(0, 2, 3, 1).double().numpy(), np.asarray(joints, dtype=np.float64),
+                        np.zeros((c["C"], 2), dtype=int), np.zeros(3), np.zeros(1), np.zeros(1), np.zeros(1),
+                        np.zeros(1), "ringA", "Frame_%03d.jpg" % i])
+    return c, inp, samples, frames

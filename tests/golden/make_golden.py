@@ -367,8 +367,21 @@ def case_predictor():
                                                                   (raw[:, 1] < hw) | (raw[:, 1] > c["H"] - hw)).sum())
         if "clamps" in c:
             assert clamps == tuple(c["clamps"]), (tag, clamps)
+        # how far the reference's float32 SVD is from the exact least-squares centre on ITS OWN inputs (the same
+        # restatement in float64): the noise level any other correct solver differs by.  The integer paths downstream
+        # (center3D.int(), centerHMs) are only meaningful to pin when their margins clear it.
+        scale = torch.tensor([c["W"] / float(c["center_size"]), c["H"] / float(c["center_size"])]).float()
+        p2 = (inter["preds"].reshape(c["C"], 2) * (scale * 2)).transpose(0, 1)
+        c64 = O.reconstruct_point(p2.double(), inter["maxvals"].double(), inp["cam"].double(), inp["intr"].double(),
+                                  inp["dist"].double())
+        noise3 = (c3.double() - c64).abs().max().item()
+        noise_px = (rp - O.reproject_point(c64.float().unsqueeze(0), inp["cam"], inp["intr"], inp["dist"])).abs().max().item()
+        assert m3 > 2 * noise3 and mr > 2 * noise_px, \
+            "ill-conditioned case: integer margins %.4f mm / %.4f px within the float32 SVD's own noise %.4f mm / %.4f px" \
+            % (m3, mr, noise3, noise_px)
         meta[tag] = dict(argmax_margin=margin, center3d_int_margin=m3,
                          center_hm_int_margin=mr, n_detect=inter["n_detect"],
+                         svd_noise_mm=noise3, svd_noise_px=noise_px,
                          center3d=c3.tolist(), clamped_xlo_xhi_ylo_yhi=list(clamps),
                          maxvals_255=[round(float(v) * 255, 3) for v in inter["maxvals"].flatten()])
         print(tag, "margins", meta[tag])

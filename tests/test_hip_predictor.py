@@ -47,8 +47,13 @@ def test_hybridnet_backbone(tag, golden):
 EDGE_TAGS = ["cfg2_partial", "cfg2_one", "cfg3_partial", "cfg2_edge", "cfg2_edge_b", "cfg3_edge", "cfg3_edge_b"]
 
 
+# the reference's default configuration (medium / medium, 320 / 320 on the shipped 72^3 grid) and the sensor-failure
+# inputs (one camera all-zero / all-one inside a valid 12-camera set)
+DEFAULT_AND_DEAD = ["default_medium_320", "cfg3_cam_black", "cfg3_cam_white"]
+
+
 @pytest.mark.parametrize("tag", ["cfg2", "cfg3", "cfg2_none", "cfg2_u8", "cfg5", "ex72", "cfg3_medium", "cfg3_large"]
-                         + EDGE_TAGS)
+                         + EDGE_TAGS + DEFAULT_AND_DEAD)
 def test_predictor3d(tag, golden):
     """JarvisPredictor3D.forward vs the imported reference's output on the same input
     (tests/golden/predictor.npz).  ex72 = the geometry the reference ships (Example_Project: 72^3 grid, V2V at
@@ -95,7 +100,7 @@ def test_predictor3d(tag, golden):
 
 
 @pytest.mark.parametrize("tag", ["ex72", "cfg3", "cfg3_medium", "cfg3_large", "cfg3_partial", "cfg3_edge",
-                                 "cfg2_partial", "cfg2_edge"])
+                                 "cfg2_partial", "cfg2_edge"] + DEFAULT_AND_DEAD)
 def test_predictor3d_time_batch_8_vs_fixture(tag, golden):
     """The time_batch >= 8 class (row-streaming BiFPN nodes: the form bench.py times) held to the REFERENCE fixture
     directly: frame 0 of an 8-frame-set call is the fixture case; the other seven are distinct subjects and

@@ -54,24 +54,25 @@ def test_reprojection(golden, tag):
         check_summary(g, tag + ".vol", vol)
 
 
-def test_reprojection_ex72_every_index(golden):
+@pytest.mark.parametrize("tag", ["ex72", "def320"])
+def test_reprojection_ex72_every_index(golden, tag):
     """The geometry the reference ships (ROI 144 / spacing 2: a 72^3 grid, 4.5 M gather indices -- too many to
     commit in full): the oracle's index field against the per-camera-plane hashes of the reference's."""
     import json
     from tests.util import index_plane_hashes
-    C, J, G, spacing = cases.REPRO_CASES["ex72"][:4]
-    inp = cases.repro_inputs("ex72")
+    C, J, G, spacing = cases.REPRO_CASES[tag][:4]
+    inp = cases.repro_inputs(tag)
     vol, idx = O.reprojection_forward(inp["hm_pad"], inp["center3d"], inp["center_hm"],
                                       inp["cam"], inp["intr"], inp["dist"],
                                       G * spacing, spacing, chunk=5, return_idx=True)
     here = os.path.dirname(os.path.abspath(__file__))
-    hashes = json.load(open(os.path.join(here, "golden", "reprojection_index_hashes.json")))["ex72"]
+    hashes = json.load(open(os.path.join(here, "golden", "reprojection_index_hashes.json")))[tag]
     assert hashes["n"] == idx.numel() == 12 * 72 ** 3
     if EXACT:
         assert index_plane_hashes(idx) == hashes["planes"]
         g = golden("reprojection")
-        check_summary(g, "ex72.idx", idx)
-        check_summary(g, "ex72.vol", vol)
+        check_summary(g, tag + ".idx", idx)
+        check_summary(g, tag + ".vol", vol)
 
 
 @pytest.mark.parametrize("tag", list(cases.V2V_CASES))
@@ -120,7 +121,8 @@ def test_hybridnet(golden, tag):
 
 
 @pytest.mark.parametrize("tag", ["cfg2", "cfg2_none", "cfg2_u8", "cfg5", "ex72", "cfg3_medium", "cfg3_large",
-                                 "cfg2_partial", "cfg2_one", "cfg3_partial", "cfg2_edge", "cfg2_edge_b", "cfg3_edge"])
+                                 "cfg2_partial", "cfg2_one", "cfg3_partial", "cfg2_edge", "cfg2_edge_b", "cfg3_edge",
+                                 "default_medium_320", "cfg3_cam_black", "cfg3_cam_white"])
 def test_predictor(golden, tag):
     c = cases.PREDICTOR_CASES[tag]
     inp = cases.predictor_inputs(tag)
@@ -177,3 +179,38 @@ def test_index_plane_hashes_pin_the_committed_fields(golden):
         bad.view(-1)[12345 % full.numel()] += 1
         assert index_plane_hashes(bad) != hashes[tag]["planes"]
     assert hashes["cfg5"]["n"] == 16 * 96 ** 3 and len(hashes["cfg5"]["planes"]) == 16
+
+
+def test_host_parity_checker():
+    """oracle.host_parity (the strict host-independent comparison smoke() and bench.py make): with the oracle's own
+    indices it reports no flips and the raw distance; with one index moved across its truncation boundary it re-runs
+    the tail with the given indices, so the distance to a result computed WITH that index is zero again."""
+    C, J, W, H, bbox, roi, spacing = 3, 5, 320, 256, 128, 64, 2
+    calib = S.ring_calibration(C, W, H, 450.0)
+    sd_c = S.efficienttrack_weights("small", 1, 70)
+    sd_h = S.hybridnet_weights("small", J, 71)
+    imgs, _, _ = S.blob_frames(calib, W, H, J, 72)
+    inter = {}
+    with torch.no_grad():
+        rp, rc = O.predictor3d_forward(sd_c, sd_h, imgs, *calib, center_size=128, bbox=bbox, roi_cube_size=roi,
+                                       grid_spacing=spacing, mean=S.MEAN, std=S.STD, intermediates=inter)
+    assert rp is not None
+    hs, G = bbox // 2 + 2, roi // spacing
+    grid = O.reprojection_grid(roi, spacing) + inter["center3d"].int()
+    idx, u, v = O.reprojection_indices(grid, *calib, inter["center_hm"], hs, G)
+    hp = O.host_parity(sd_h, inter, idx, rp, rp, calib, roi, spacing, bbox)
+    assert hp["flips"] == 0 and hp["raw_mm"] == 0.0 and hp["same_indices_mm"] == 0.0
+    # move the voxel whose u/2 is closest to an integer from above one column to the left
+    half = u / 2
+    d = (half - half.floor())
+    d[half < 1] = 1.0
+    pos = tuple(int(i) for i in (d == d.min()).nonzero()[0])
+    moved = idx.clone()
+    moved[pos] -= 1
+    with torch.no_grad():
+        pts_moved, _ = O.tail_with_indices(sd_h, inter["heatmaps_padded"], moved, inter["center3d"].int()[None],
+                                           roi, spacing)
+    hp = O.host_parity(sd_h, inter, moved, pts_moved, rp, calib, roi, spacing, bbox)
+    assert hp["flips"] == 1 and hp["same_indices_mm"] == 0.0
+    r = hp["flip_voxels"][0]
+    assert tuple(r["voxel"]) == pos and abs(r["dist_to_integer"] - float(d.min())) < 1e-6

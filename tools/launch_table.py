@@ -1,7 +1,7 @@
 """Every launch of one time batch, in launch order, with its median HIP-event duration (one stream, kernels timed
 alone) -- the per-launch view behind bench.py's per-kernel-name table.
 
-    python tools/launch_table.py [--config cfg3] [--model-size small] [-T 32] [--out file.tsv] [--group]
+    python tools/launch_table.py [--config cfg3] [--model-size small] [-T 32] [--out file.tsv]
 """
 import argparse
 import os
@@ -14,13 +14,14 @@ from jarvis_hybridnet_amd._predictor import NativePredictor  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="cfg3")
-ap.add_argument("--model-size", default="small")
+ap.add_argument("--model-size", default=None)
 ap.add_argument("-T", type=int, default=None)
 ap.add_argument("--passes", type=int, default=5)
 ap.add_argument("--out", default=None)
 ap.add_argument("--precision", default=None)
 a = ap.parse_args()
 c = bench.CONFIGS[a.config]
+a.model_size = a.model_size or c.get("size", "small")
 T = a.T or c["time_batch"]
 calib = S.ring_calibration(c["C"], c["W"], c["H"], c["focal"])
 sd_c = S.efficienttrack_weights(a.model_size, 1, c["seeds"][0])

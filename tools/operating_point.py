@@ -6,9 +6,8 @@
 
 Same workload, weights and frame sets as bench.py's headline (BASELINE configs[2], frames resident in HBM as
 fp32); one cell = K MultiStreamPredictor streams x T frame sets each, timed like bench.py's step loop (wall clock
-between two device synchronisations over enough steps to cover >= `--seconds`).  Writes one JSON table; the HBM
-traffic of chosen cells is collected separately under rocprofv3 --pmc (tools/pmc_traffic.sh with
-JH_BENCH_ARGS="--time-batch T --streams K").
+between two device synchronisations over enough steps to cover >= `--seconds`).  Writes one JSON table.  (HBM
+traffic is collected separately under rocprofv3 --pmc by tools/pmc_traffic.sh, at the benched time batch on one stream.)
 """
 import argparse
 import json
