@@ -88,9 +88,10 @@ def usable_cores():
 
 
 def kernel_family(name):
-    """Which roofline bounds a profiled launch, by kernel FAMILY (not by name prefix): the MFMA convolutions
+    """Which rooflines can bound a profiled launch, by kernel FAMILY (not by name prefix): the MFMA convolutions
     (`conv_mfma_kernel`, the Winograd / bf16x3 / fused ConvTranspose kernels -- all named conv{2,3}d_*) are priced
-    against the matrix-core peak of their arithmetic type; everything else -- the vector-ALU stem (`stem_conv_*`:
+    against the matrix-core peak of their arithmetic type AND against HBM, whichever floor is higher (kernel_table);
+    everything else -- the vector-ALU stem (`stem_conv_*`:
     HBM-bound on the frame rows it fetches), the one-channel CenterDetect head (`deconv_*_c1`), fused BiFPN nodes,
     InstanceNorm passes, depthwise convolutions, the reprojection gather, argmax / soft-argmax -- against HBM."""
     return "mfma" if name.startswith(("conv2d_", "conv3d_")) else "hbm"
@@ -129,13 +130,29 @@ def kernel_table(recs, passes, top=10):
     for name, r in sorted(rows.items(), key=lambda kv: -kv[1]["ms"]):
         s = r["ms"] * 1e-3
         if r["flops"] > 0 and kernel_family(name) == "mfma":
+            # a convolution is bound by whichever floor is HIGHER: the matrix cores (executed FLOPs / peak) or HBM
+            # (algorithmic bytes: one read of the input, one write of the output, the weights / 8 TB/s) -- the
+            # few-channel 1x1 and stem-side layers are HBM-bound, pricing them against the matrix peak hid their
+            # head-room.  Both fractions are printed; `frac` is the binding one.
             ex = executed_flops(name, r["flops"])
             peak = PEAK_BF16_MFMA_TFLOPS if "bf16x3" in name else PEAK_F32_MFMA_TFLOPS
-            row = dict(kernel=name, bound="mfma", achieved=ex / s / 1e12, peak=peak,
-                       unit="TFLOP/s", frac=ex / s / 1e12 / peak, algorithmic_equiv=r["flops"] / s / 1e12)
+            t_mfma, t_hbm = ex / (peak * 1e12), r["bytes"] / (PEAK_HBM_GBS * 1e9)
+            fm, fh = t_mfma / s, t_hbm / s
+            if t_hbm > t_mfma:
+                row = dict(kernel=name, bound="hbm", achieved=r["bytes"] / s / 1e9, peak=PEAK_HBM_GBS, unit="GB/s",
+                           frac=fh, frac_mfma=fm, frac_hbm=fh)
+            else:
+                row = dict(kernel=name, bound="mfma", achieved=ex / s / 1e12, peak=peak, unit="TFLOP/s", frac=fm,
+                           frac_mfma=fm, frac_hbm=fh, algorithmic_equiv=r["flops"] / s / 1e12)
         else:
             row = dict(kernel=name, bound="hbm", achieved=r["bytes"] / s / 1e9, peak=PEAK_HBM_GBS,
                        unit="GB/s", frac=r["bytes"] / s / 1e9 / PEAK_HBM_GBS)
+        if name.startswith("stem_conv"):
+            # which floor `algorithmic_bytes` is for the fused resize / crop + stem: the bytes of the taps themselves.  The
+            # no-antialias 1280 -> 256 resize touches 1 pixel in 5 on 2 rows in 4, and HBM delivers 64-byte sectors: the
+            # sector-granular floor of fp32 frames is ~1.9x the tap bytes (PMC: profiles/*_pmc_traffic.json), so against
+            # THAT floor the resize stem sits at ~2x the fraction printed here; uint8 frames are 4x lighter
+            row["bytes_floor"] = "tap bytes (not sector-granular)"
         row.update(ms_per_step=r["ms"], launches_per_step=r["n"], avg_launch_ms=r["ms"] / r["n"],
                    share_of_step=r["ms"] / total, algorithmic_flops_per_launch=r["flops"] / r["n"],
                    algorithmic_bytes_per_launch=r["bytes"] / r["n"])

@@ -10,7 +10,9 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libjarvis_hip.so")
+# JH_LIBRARY_PATH: another build of the SAME library (tests/host_sanitize: the host halves under ASan / UBSan against a
+# malloc-backed HIP stand-in).  Not a fallback: whatever is named must exist and export every symbol.
+LIB_PATH = os.environ.get("JH_LIBRARY_PATH") or os.path.join(_HERE, "libjarvis_hip.so")
 _lib = None
 
 c_void_p, c_int, c_float, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64

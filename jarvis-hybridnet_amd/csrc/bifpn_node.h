@@ -28,6 +28,7 @@ struct NodeArgs {
 
 // csrc/bifpn_rows.hip: will this node take the row-streaming form?  (host; also used when a plan is built)
 bool bifpn_rows_eligible(const NodeArgs& a);
+bool bifpn_rows_ragged88(const NodeArgs& a);    // 88 channels, class >= 8, width no multiple of 16: workgroup form
 
 #if defined(__HIPCC__)
 constexpr int kNodeTY = 8, kNodeTX = 16, kNodePY = 10, kNodePX = 18, kNodeNRG = 4;

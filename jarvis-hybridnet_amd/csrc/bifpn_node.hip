@@ -555,7 +555,7 @@ int launch_bifpn_node(const NodeArgs& args, hipStream_t s) {
   if (JH_ENV_KNOB("JH_NODE_ABL") >= 0) a.abl = JH_ENV_KNOB("JH_NODE_ABL");   // timing experiments only
   const size_t head = ((size_t)3 * a.Cp * 2 + (size_t)9 * a.Cp) * sizeof(float);
   const size_t at_bytes = (size_t)128 * (a.Cp + 4) * sizeof(float);
-  const size_t red = (size_t)8 * kNodeNRG * 16 * 2 * sizeof(float);
+  const size_t red = (size_t)8 * kNodeNRG * 16 * 2 * sizeof(double);   // conv_epilogue: fp64 partials
   const size_t halo_px = (size_t)kNodePY * kNodePX * sizeof(float);
   // preferred: the whole channel range in one halo chunk, operand tile aliased onto it
   // (3 workgroups per CU for the 56-channel pyramid of the small model)

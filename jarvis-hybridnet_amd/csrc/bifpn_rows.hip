@@ -363,14 +363,22 @@ int launch_bifpn_rows_wg(const NodeArgs& a, hipStream_t s);
 bool bifpn_rows_ps_ok(const NodeArgs& a, int seg_rows, int strips, int segs);      // csrc/bifpn_rows_ps.hip
 int launch_bifpn_rows_ps(const NodeArgs& a, int seg_rows, int strips, int segs, hipStream_t s);
 
+// 88 channels, time-batch class >= 8, a level whose width is no multiple of 16 (or below 16): the one-wave / pair forms
+// need whole 16-pixel strips, the tile kernel's path for more than 64 channels is slow whatever the level -- the
+// workgroup form masks the last strip's pixels past the row end.  The reference's DEFAULT geometry (320-pixel images:
+// levels 80 / 40 / 20 / 10 / 5) has four of its five levels here.  A function of the node only.  JH_NODE_ROWS88_RAGGED=0: off.
+bool bifpn_rows_ragged88(const NodeArgs& a) {
+  return a.Cp == 88 && a.rows == 1 && (a.W % 16 != 0 || a.W < 16) && JH_ENV_KNOB("JH_NODE_ROWS88_RAGGED") != 0;
+}
+
 bool bifpn_rows_eligible(const NodeArgs& a) {
   if (JH_ENV_KNOB("JH_NODE_ROWS") == 0 || a.rows == 0) return false;
   // (160 channels, the large model: the workgroup form, csrc/bifpn_rows_wg.hip; JH_NODE_ROWS160=0: tile form.
   //  a.rows == 2 -- the wide pyramids at time batches below 8 -- is the same form with 8-row segments, also at 88
   //  channels, where one wave per strip is the faster form at bench scale but far too slow per row for a few images)
   if (a.rows == 2 && JH_ENV_KNOB("JH_NODE_ROWS_LAT") == 0) return false;
-  const bool wg = (a.Cp == 160 || (a.Cp == 88 && a.rows == 2)) && JH_ENV_KNOB("JH_NODE_ROWS160") != 0 &&
-                  bifpn_rows_wg_shape_ok(a);
+  const bool wg = (a.Cp == 160 || (a.Cp == 88 && (a.rows == 2 || bifpn_rows_ragged88(a)))) &&
+                  JH_ENV_KNOB("JH_NODE_ROWS160") != 0 && bifpn_rows_wg_shape_ok(a);
   if (a.rows == 2 && !wg) return false;
   if (a.Cp != 56 && !(a.Cp == 88 && JH_ENV_KNOB("JH_NODE_ROWS88") != 0) && !wg) return false;
   // (88 / 160 channels: also the 16-pixel-wide level -- one strip per image -- because the tile kernel's path for more
@@ -440,7 +448,7 @@ static int launch_rows_rc(const NodeArgs& a, hipStream_t s) {
 }
 
 int launch_bifpn_rows(const NodeArgs& a, hipStream_t s) {
-  if (a.Cp == 160 || a.rows == 2) return launch_bifpn_rows_wg(a, s);
+  if (a.Cp == 160 || a.rows == 2 || bifpn_rows_ragged88(a)) return launch_bifpn_rows_wg(a, s);
   if (a.Cp == 88) return launch_rows_rc<88>(a, s);
   return launch_rows_rc<56>(a, s);
 }

@@ -312,7 +312,9 @@ static int launch_rows_wg_rc(const NodeArgs& a, hipStream_t s) {
   //  weight slices, the statistics' fp64 arithmetic, two warm-up rows) is paid once per 64 rows instead of per 16 or 32:
   //  measured at 160 channels, 384 images: P3 node 1.218 -> 1.133 ms, head 1.270 -> 1.024, P4 0.331 -> 0.292 / 0.431 ->
   //  0.389; the 16-pixel levels keep 8 rows, 0.106 against 0.112 with 16)
-  if (a.rows != 2 && JH_ENV_KNOB("JH_NODE_SEG") <= 0 && a.H >= 32) seg_rows = a.H;
+  //  (88 channels on a ragged level -- bifpn_rows_ragged88 -- keep half-image segments: 192 images x 3 strips of a 40-pixel
+  //  level are 576 workgroups on 512 slots with one segment per strip)
+  if (a.rows != 2 && JH_ENV_KNOB("JH_NODE_SEG") <= 0 && a.H >= 32 && !bifpn_rows_ragged88(a)) seg_rows = a.H;
   seg_rows = (seg_rows + 1) & ~1;
   if (seg_rows > a.H) seg_rows = a.H;
   const int segs = (a.H + seg_rows - 1) / seg_rows;

@@ -238,7 +238,7 @@ int pack_bf16x3_weights(int cin, int cout, const float* w, const float* b, ConvW
 template <int NCB>
 static int launch_b3(const B3Args& a, int groups, hipStream_t s) {
   using namespace b3;
-  const size_t lds = (size_t)2 * PLANE + (size_t)2 * a.cin_p * sizeof(float) + (size_t)4 * NCB * 16 * 2 * sizeof(float);
+  const size_t lds = (size_t)2 * PLANE + (size_t)2 * a.cin_p * sizeof(float) + (size_t)4 * NCB * 16 * 2 * sizeof(double);
   dim3 grid(a.tiles_x * a.tiles_y * a.tiles_z, a.N, groups);
   hipLaunchKernelGGL(conv3d_bf16x3_kernel<NCB>, grid, dim3(256), lds, s, a);
   JH_CHECK_HIP(hipGetLastError());

@@ -61,7 +61,7 @@ struct XGeom {
     return ((mr / TY) * S * PY + (mr % TY) * S) * PXS;
   }
   static size_t lds_bytes(int cin_p, int ncb) {
-    return (size_t)2 * PLANE + (size_t)2 * cin_p * sizeof(float) + (size_t)4 * ncb * 16 * 2 * sizeof(float);
+    return (size_t)2 * PLANE + (size_t)2 * cin_p * sizeof(float) + (size_t)4 * ncb * 16 * 2 * sizeof(double);
   }
 };
 

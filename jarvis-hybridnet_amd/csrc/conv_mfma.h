@@ -54,7 +54,7 @@ struct EpilogueArgs {
 
 // Shared epilogue of the MFMA kernels: bias, store of the raw output, and the
 // per-channel sum / sum of squares of the tile (registers -> wave shuffles -> LDS ->
-// one fp64 atomic pair per channel and workgroup).  `red` is >= NW*NR*16*2 floats of LDS
+// one fp64 atomic pair per channel and workgroup).  `red` is >= NW*NR*16*2 DOUBLES of LDS, 8-byte aligned
 // (NW = waves per workgroup).
 // exchange with the lane whose index differs in bit 0 / bit 1 (DPP quad permutes)
 __device__ __forceinline__ float quad_xor1(float v) {
@@ -71,26 +71,17 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[MR][NR], const Epilog
                                               int tid) {
   const int lane = tid & 63, wave = tid >> 6, mrow = lane & 15, kq = lane >> 4;
   const int j = lane & 3;                  // position inside the lane quad
+  double* redd = reinterpret_cast<double*>(red);   // NW * NR * 16 * 2 doubles (callers size and 8-byte-align `red` for it)
 #pragma unroll
   for (int nr = 0; nr < NR; ++nr) {
     const int ch = (nb0 + nr) * 16 + mrow;
     const bool ch_ok = ch < e.cout_p;
     const float bv = (e.bias && ch < e.cout_p16) ? e.bias[ch] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) {
       float v[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int p = (wave * MR + mr) * 16 + kq * 4 + r;
-        const int tx = p % TX, ty = (p / TX) % TY, tz = p / (TX * TY);
-        v[r] = acc[mr][nr][r] + bv;
-        // (FULL: no test at all -- channels past cout have zero weights and zero bias, their values are 0)
-        if (FULL || (ch_ok && oz0 + tz < e.Dout && oy0 + ty < e.Hout && ox0 + tx < e.Wout)) {
-          s1 += v[r];
-          s2 += v[r] * v[r];
-        }
-      }
+      for (int r = 0; r < 4; ++r) v[r] = acc[mr][nr][r] + bv;
       // The MFMA result has 4 pixels x 1 channel per lane.  Transpose 4x4 inside each
       // lane quad so a lane holds 1 pixel x 4 consecutive channels: one 16-byte store
       // instead of four 4-byte stores (the epilogue is store-issue bound).
@@ -110,12 +101,51 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[MR][NR], const Epilog
             e.y + ((size_t)((oz * e.osz + e.offz) * e.Hy + (oy * e.os + e.offy)) * e.Wy + (ox * e.os + e.offx)) * e.cout_p + c0) =
             make_float4(v[0], v[1], v[2], v[3]);
     }
+    // Statistics partials of this lane, handed on as DOUBLES (jh_common.h: stat_add(double)): accumulated in packed
+    // fp32 around a per-lane PIVOT (the lane's first value: sums of v - m and (v - m)^2, whose rounding errors scale
+    // with the spread of the data instead of its mean), un-shifted in fp64 once per lane and column block:
+    //   sum v = n m + sum d,   sum v^2 = n m^2 + 2 m sum d + sum d^2.
+    // 1.5 packed instructions per value + 8 fp64 ones per lane (all-fp64 accumulation measured +20 % on the few-channel
+    // layers: conv2d_k1s1_16x8@128 0.146 -> 0.182 ms).  Behind the stores: they drain while this runs.
+    double s1 = 0.0, s2 = 0.0;
+    if (e.stats) {
+      typedef float sf2 __attribute__((ext_vector_type(2)));
+      const float m = acc[0][nr][0] + bv;
+      const sf2 m2 = (sf2){m, m};
+      sf2 t1a = (sf2){0.f, 0.f}, t1b = t1a, t2a = t1a, t2b = t1a;
+      int cnt = FULL ? MR * 4 : 0;
+#pragma unroll
+      for (int mr = 0; mr < MR; ++mr) {
+        sf2 da = (sf2){acc[mr][nr][0] + bv, acc[mr][nr][1] + bv} - m2;
+        sf2 db = (sf2){acc[mr][nr][2] + bv, acc[mr][nr][3] + bv} - m2;
+        if (!FULL) {
+          bool ok[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int p = (wave * MR + mr) * 16 + kq * 4 + r;
+            const int tx = p % TX, ty = (p / TX) % TY, tz = p / (TX * TY);
+            ok[r] = ch_ok && oz0 + tz < e.Dout && oy0 + ty < e.Hout && ox0 + tx < e.Wout;
+            cnt += ok[r] ? 1 : 0;
+          }
+          da = (sf2){ok[0] ? da[0] : 0.f, ok[1] ? da[1] : 0.f};
+          db = (sf2){ok[2] ? db[0] : 0.f, ok[3] ? db[1] : 0.f};
+        }
+        // (FULL: no test at all -- channels past cout have zero weights and zero bias, their values are 0)
+        t1a += da; t1b += db;
+        t2a = __builtin_elementwise_fma(da, da, t2a);
+        t2b = __builtin_elementwise_fma(db, db, t2b);
+      }
+      const sf2 t1 = t1a + t1b, t2 = t2a + t2b;
+      const double md = (double)m, nd = (double)cnt, d1 = (double)(t1[0] + t1[1]), d2 = (double)(t2[0] + t2[1]);
+      s1 = fma(nd, md, d1);
+      s2 = fma(md, fma(nd, md, 2.0 * d1), d2);
+    }
     if (e.stats) {
       s1 = sum_xor16(s1); s2 = sum_xor16(s2);
       s1 = sum_xor32(s1); s2 = sum_xor32(s2);
       if (kq == 0) {
-        red[(wave * NR * 16 + nr * 16 + mrow) * 2 + 0] = s1;
-        red[(wave * NR * 16 + nr * 16 + mrow) * 2 + 1] = s2;
+        redd[(wave * NR * 16 + nr * 16 + mrow) * 2 + 0] = s1;
+        redd[(wave * NR * 16 + nr * 16 + mrow) * 2 + 1] = s2;
       }
     }
   }
@@ -124,11 +154,11 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[MR][NR], const Epilog
     if (tid < NR * 16) {
       const int ch = nb0 * 16 + tid;
       if (ch < e.cout_p) {
-        float s1 = 0.f, s2 = 0.f;
+        double s1 = 0.0, s2 = 0.0;
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
-          s1 += red[(w * NR * 16 + tid) * 2 + 0];
-          s2 += red[(w * NR * 16 + tid) * 2 + 1];
+          s1 += redd[(w * NR * 16 + tid) * 2 + 0];
+          s2 += redd[(w * NR * 16 + tid) * 2 + 1];
         }
         stat_add(e.stats + (size_t)ch * kStatW, s1, s2);
       }
@@ -700,7 +730,7 @@ template <int ND, int K, int STRIDE, int TZ, int TY, int TX, int NRV, int KC8V>
 int launch_conv_inst(const ConvArgs& b, dim3 grid, hipStream_t s) {
   using G = ConvGeom<ND, K, STRIDE, TZ, TY, TX>;
   size_t lds = G::lds_bytes(KC8V * 8);
-  const size_t red = (size_t)4 * 4 * 16 * 2 * sizeof(float);
+  const size_t red = (size_t)4 * 4 * 16 * 2 * sizeof(double);       // conv_epilogue: fp64 partials
   if (lds < red) lds = red;
   lds += (size_t)b.nrm_floats * sizeof(float);
   JH_REQUIRE(lds <= 160 * 1024, "conv patch does not fit LDS");

@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void deconv4_fused_kernel(const ConvArgs a) {
 template <int NRP, int KC8, bool TR>
 static int launch_deconv4_tr(const ConvArgs& a, hipStream_t s) {
   size_t lds = (size_t)kDNPIX * (KC8 * 8 + kDSPAD) * sizeof(float);
-  const size_t red = (size_t)4 * 4 * 16 * 2 * sizeof(float);
+  const size_t red = (size_t)4 * 4 * 16 * 2 * sizeof(double);
   if (lds < red) lds = red;
   lds += (size_t)a.nrm_floats * sizeof(float);
   auto kern = deconv4_fused_kernel<NRP, KC8, TR>;

@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void depthwise_lds_kernel(
   const int c4 = tid & (QN - 1);                   // fixed channel quad of this thread
   const bool active = c4 < q;
   __syncthreads();
-  df2 s1l = (df2){0.f, 0.f}, s1h = s1l, s2l = s1l, s2h = s1l;
+  double d1[4] = {0.0, 0.0, 0.0, 0.0}, d2[4] = {0.0, 0.0, 0.0, 0.0};     // fp64 partials (jh_common.h: stat_acc)
   static_assert(!POOL || SL == 64, "the fused pooled sums keep a thread's one strip in registers");
   df2 al[4], ah[4];                                // packed fp32 FMAs: two channels per instruction
   unsigned okm = 0;                                // (POOL) which of the strip's four pixels are inside the image
@@ -342,8 +342,8 @@ __global__ __launch_bounds__(256) void depthwise_lds_kernel(
         if (oy < H && ox < W) {
           *reinterpret_cast<df4*>(y + (((size_t)n * H + oy) * W + ox) * Cp + c0 + c4 * 4) =
               (df4){al[o][0], al[o][1], ah[o][0], ah[o][1]};
-          s1l += al[o]; s1h += ah[o];
-          s2l += al[o] * al[o]; s2h += ah[o] * ah[o];
+          stat_acc(d1[0], d2[0], al[o][0]); stat_acc(d1[1], d2[1], al[o][1]);
+          stat_acc(d1[2], d2[2], ah[o][0]); stat_acc(d1[3], d2[3], ah[o][1]);
           okm |= 1u << o;
         }
       }
@@ -351,40 +351,42 @@ __global__ __launch_bounds__(256) void depthwise_lds_kernel(
   }
   if (stats) {
     __syncthreads();                               // the patch is dead: reuse LDS for the reduce
-    // [SL rows][QN quads][2][4]; fixed-order two-level sum (8 threads x SL / 8 rows, then 8 partials)
-    df4* p = reinterpret_cast<df4*>(sm) + ((size_t)(tid >> QS) * QN + c4) * 2;
-    p[0] = (df4){s1l[0], s1l[1], s1h[0], s1h[1]};
-    p[1] = (df4){s2l[0], s2l[1], s2h[0], s2h[1]};
-    float* red2 = sm + SL * QN * 8;                // [QN * 8 values][8 parts]
+    // [SL rows][QN quads][2][4] doubles; fixed-order two-level sum (8 threads x SL / 8 rows, then 8 partials)
+    double* smd = reinterpret_cast<double*>(sm);
+    double* p = smd + ((size_t)(tid >> QS) * QN + c4) * 8;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { p[k] = d1[k]; p[4 + k] = d2[k]; }
+    double* red2 = smd + SL * QN * 8;              // [QN * 8 values][8 parts]
     __syncthreads();
     for (int i = tid; i < q * 8 * 8; i += 256) {
       const int part = i & 7, val = i >> 3;        // val = (quad, sum / sum of squares, component)
       const int comp = val & 3, sq = (val >> 2) & 1, cq = val >> 3;
-      float acc = 0.f;
+      double acc = 0.0;
 #pragma unroll
-      for (int r = 0; r < SL / 8; ++r) acc += sm[(((size_t)(part * (SL / 8) + r) * QN + cq) * 2 + sq) * 4 + comp];
+      for (int r = 0; r < SL / 8; ++r) acc += smd[(((size_t)(part * (SL / 8) + r) * QN + cq) * 2 + sq) * 4 + comp];
       red2[val * 8 + part] = acc;
     }
     __syncthreads();
-    float* tot = red2 + QN * 8 * 8;                // (POOL) [QN * 8] totals of the image, then [CC] mean, [CC] rstd
+    double* tot = red2 + QN * 8 * 8;               // (POOL) [QN * 8] totals of the image, then [CC] mean, [CC] rstd
     for (int i = tid; i < q * 8; i += 256) {
       const int comp = i & 3, sq = (i >> 2) & 1, cq = i >> 3;
-      float acc = 0.f;
+      double acc = 0.0;
 #pragma unroll
       for (int r = 0; r < 8; ++r) acc += red2[i * 8 + r];
-      exact_add(stats + (((size_t)n * Cp + c0 + cq * 4 + comp) * 2 + sq) * kLimbs, (double)acc);
+      exact_add_rounded(stats + (((size_t)n * Cp + c0 + cq * 4 + comp) * 2 + sq) * kLimbs, acc);
       if (POOL) tot[i] = acc;
     }
     if (POOL) {
       // the image is one tile: `tot` ARE its statistics (the only contribution to stats[n][c]); mean / rstd exactly
       // as norm_apply_kernel derives them from the accumulators
-      float* mr = tot + QN * 8;
+      float* mr = reinterpret_cast<float*>(tot + QN * 8);
+      float* red2f = reinterpret_cast<float*>(red2);     // the pooled sums (plain sums of bounded terms) stay fp32
       __syncthreads();
       if (tid < q * 4) {
         const int cq = tid >> 2, comp = tid & 3;
         const double P = (double)(H * W);
-        const double mu = (double)tot[(cq * 2 + 0) * 4 + comp] / P;
-        double var = (double)tot[(cq * 2 + 1) * 4 + comp] / P - mu * mu;
+        const double mu = tot[(cq * 2 + 0) * 4 + comp] / P;
+        double var = tot[(cq * 2 + 1) * 4 + comp] / P - mu * mu;
         if (var < 0.0) var = 0.0;
         mr[tid] = (float)mu;
         mr[CC + tid] = (float)(1.0 / sqrt(var + 1e-5));
@@ -411,13 +413,13 @@ __global__ __launch_bounds__(256) void depthwise_lds_kernel(
         float acc = 0.f;
 #pragma unroll
         for (int r = 0; r < SL / 8; ++r) acc += sm[((size_t)(part * (SL / 8) + r) * QN + (val >> 2)) * 4 + (val & 3)];
-        red2[val * 8 + part] = acc;
+        red2f[val * 8 + part] = acc;
       }
       __syncthreads();
       for (int i = tid; i < q * 4; i += 256) {
         float acc = 0.f;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) acc += red2[i * 8 + r];
+        for (int r = 0; r < 8; ++r) acc += red2f[i * 8 + r];
         exact_add(pool + ((size_t)n * Cp + c0 + i) * kLimbs, (double)acc);
       }
     }
@@ -436,7 +438,7 @@ int launch_depthwise(const Act& x, const float* w, int k, float* y, double* stat
     dim3 grid(1, (x.Cp + 15) / 16, x.N);
     const int ht = 16 + k - 1;
     size_t lds = (size_t)(ht * ht * (16 + 4) + k * k * 16) * sizeof(float);
-    const size_t red = (size_t)(64 * 4 * 8 + 4 * 8 * 8 + 4 * 8 + 2 * 16) * sizeof(float);
+    const size_t red = (size_t)(64 * 4 * 8 + 4 * 8 * 8 + 4 * 8) * sizeof(double) + 2 * 16 * sizeof(float);
     if (lds < red) lds = red;
     if (k == 3) hipLaunchKernelGGL((depthwise_lds_kernel<3, 16, true>), grid, dim3(256), lds, s, x.p, w, y, stats, x.H, x.W, x.Cp, pool);
     else hipLaunchKernelGGL((depthwise_lds_kernel<5, 16, true>), grid, dim3(256), lds, s, x.p, w, y, stats, x.H, x.W, x.Cp, pool);
@@ -450,7 +452,7 @@ int launch_depthwise(const Act& x, const float* w, int k, float* y, double* stat
   dim3 grid(tiles, (x.Cp + cc - 1) / cc, x.N);
   const int ht = 16 + k - 1;
   size_t lds = (size_t)(ht * ht * (cc + 4) + k * k * cc) * sizeof(float);
-  const size_t red = (size_t)((256 / (cc / 4)) * (cc / 4) * 8 + (cc / 4) * 8 * 8) * sizeof(float);
+  const size_t red = (size_t)((256 / (cc / 4)) * (cc / 4) * 8 + (cc / 4) * 8 * 8) * sizeof(double);
   if (lds < red) lds = red;
 #define JH_DW(K, CC) hipLaunchKernelGGL((depthwise_lds_kernel<K, CC>), grid, dim3(256), lds, s, x.p, w, y, stats, x.H, x.W, x.Cp)
   if (k == 3) { if (cc == 32) JH_DW(3, 32); else JH_DW(3, 16); }

@@ -246,6 +246,37 @@ __device__ __forceinline__ void stat_add(double* st, float s1, float s2) {
   exact_add(st, (double)s1);
   exact_add(st + kLimbs, (double)s2);
 }
+// The 2D networks' producers hand over DOUBLE partials (round 6).  variance = E[x^2] - mean^2 cancels: with fp32
+// partial sums a channel whose variance is a small fraction r of its mean square -- a constant frame from a dead or
+// saturated camera, where only the zero padding of each layer varies: r ~ 1e-2..1e-3 -- gets rstd to ~1e-7 / r, layer
+// after layer (fixture cfg3_cam_black: 0.012 mm on the 3D keypoints; the reference accumulates in double,
+// at::acc_type<float>).  Squares of fp32 values are exact in fp64 and a workgroup's few thousand addends lose nothing.
+// A double partial through exact_add would light up two or three limbs -- two or three atomics per value where an fp32
+// partial needs one, and the few-channel high-resolution layers are bound by exactly those atomics (64 workgroups per
+// image adding to the same 16 addresses: conv2d_k1s1_16x8@128 0.146 -> 0.182 ms).  So a double partial is ROUNDED to one
+// limb, chosen by its magnitude (a function of the addend alone: still order-independent): windows of ten binary
+// orders with at least 30 bits below the window's lower end -- relative precision 2^-31 or better for |p| >= 2^-5
+// (fp32: 2^-24), absolute 2^-36 below that (far under eps = 1e-5 per pixel).  Every limb's addends are multiples of its
+// grid and below 2^40 grid steps, so every addition stays exact for up to 2^13 addends per (n, c) as before.
+__device__ __forceinline__ void exact_add_rounded(double* dst, double p) {
+  const double a = fabs(p);
+  double q;
+  int slot;
+  if (a < 0x1p5) { q = rint(p * 0x1p35) * 0x1p-35; slot = 2; }
+  else if (a < 0x1p15) { q = rint(p * 0x1p25) * 0x1p-25; slot = 1; }
+  else { q = rint(p * 0x1p15) * 0x1p-15; slot = 0; }
+  if (q != 0.0) unsafeAtomicAdd(dst + slot, q);
+}
+__device__ __forceinline__ void stat_add(double* st, double s1, double s2) {
+  exact_add_rounded(st, s1);
+  exact_add_rounded(st + kLimbs, s2);
+}
+// one value's contribution to a lane's (sum, sum of squares): cvt + add + fma, all full-rate fp64
+__device__ __forceinline__ void stat_acc(double& s1, double& s2, float v) {
+  const double d = (double)v;
+  s1 += d;
+  s2 = fma(d, d, s2);
+}
 #endif
 
 #if defined(__HIPCC__)
@@ -289,6 +320,19 @@ __device__ __forceinline__ float sum_xor16(float s) {
 __device__ __forceinline__ float sum_xor32(float s) {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// ... and the same steps for fp64 partials (two 32-bit swaps per step)
+__device__ __forceinline__ double sum_xor16(double s) {
+  const unsigned lo = (unsigned)__double2loint(s), hi = (unsigned)__double2hiint(s);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+__device__ __forceinline__ double sum_xor32(double s) {
+  const unsigned lo = (unsigned)__double2loint(s), hi = (unsigned)__double2hiint(s);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
 }
 // x * sigmoid(x) with the hardware exp2 and reciprocal (about 1e-7 relative error).  `__fdividef` is a
 // full IEEE division under this build's flags (v_div_scale / v_div_fmas / v_div_fixup: ten instructions).

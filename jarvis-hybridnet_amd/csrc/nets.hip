@@ -453,7 +453,7 @@ int EffTrackPlan::node(const ParamMap& pm, const std::string& cp, int n_in, cons
     pooled->a = Act{};
     // (160 channels, csrc/bifpn_rows_wg.hip: also the node with three same-level inputs, so the bottom-up pass stays in
     //  the row-streaming form one level further down)
-    const bool same3 = n_in == 3 && modes[1] == FUSE_SAME && modes[2] == FUSE_SAME && (like.Cp == 160 || a.rows == 2);
+    const bool same3 = n_in == 3 && modes[1] == FUSE_SAME && modes[2] == FUSE_SAME && (like.Cp == 160 || a.rows == 2 || bifpn_rows_ragged88(a));
     if ((n_in == 2 || same3) && act == ACT_SILU && out->a.Cp == like.Cp && like.H % 2 == 0 && bifpn_rows_eligible(a)) {
       if (new_act(like.N, 1, like.H / 2, like.W / 2, cout, &pooled->a)) return 1;
       pooled->st = (long)st; pooled->inv = out->inv; pooled->act = out->act;

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
   //  35.8 KB of LDS = twice the workgroups per CU; the kernel is bound by the latency of its patch loads)
   __shared__ __attribute__((aligned(16))) float4 patch[kStP * kStP > CO * 64 ? kStP * kStP : CO * 64];
   float* red = reinterpret_cast<float*>(patch);      // statistics: [channel][thread]
-  __shared__ float red2[2 * CO * 16];
+  __shared__ double red2[2 * CO * 16];               // fp64 partials (jh_common.h: stat_acc)
   const int tid = threadIdx.x;
   const int Ho = H >> 1, Wo = W >> 1;
   const int tiles_x = (Wo + kStT - 1) / kStT;
@@ -130,19 +130,15 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
 #pragma unroll
     for (int cg = 0; cg < CO / 16; ++cg) {             // (16 channels x 16 parts per round of the 256 threads)
       const int c = cg * 16 + (tid >> 4), part = tid & 15;
-      float s1 = 0.f, s2 = 0.f;
+      double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float v = red[c * 256 + part * 16 + i];
-        s1 += v;
-        s2 = fmaf(v, v, s2);
-      }
+      for (int i = 0; i < 16; ++i) stat_acc(s1, s2, red[c * 256 + part * 16 + i]);
       red2[(c * 16 + part) * 2 + 0] = s1;
       red2[(c * 16 + part) * 2 + 1] = s2;
     }
     __syncthreads();
     if (tid < CO) {
-      float s1 = 0.f, s2 = 0.f;
+      double s1 = 0.0, s2 = 0.0;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         s1 += red2[(tid * 16 + i) * 2 + 0];
