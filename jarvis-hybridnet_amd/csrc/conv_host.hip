@@ -211,8 +211,24 @@ int launch_conv(const ConvDesc& d, const ConvWeights& w, const Act& x, const Act
                (d.k == 1 || d.k == 3)) ? 1 : 0;   // (measured: stride-2 layers do not gain)
     if (JH_ENV_KNOB("JH_CONV2D_BIG") == 0) big = 0;
     if (big) return conv_launch_2d_big(a, d.k, d.stride, nr, budget, s);
+    // Pointwise layers on images that do not tile into 8 x 16 (the reference's DEFAULT 320-pixel geometry: 20 x 20 at
+    // stride 16 fills 52 % of its 3 x 2 tiles, 10 x 10 39 %): a 1 x 1 convolution has no neighbourhood, so the image
+    // is handed over as one row of H * W pixels and cut into 1 x 128 tiles (20 x 20: 78 %, 40 x 40: 96 %).  A function
+    // of the layer's shape only (the tiling is part of the fused statistics' fp32 arithmetic).  JH_CONV_K1_FLAT=0: off.
+    if (d.k == 1 && d.stride == 1 && d.ostride == 1 && d.nphase == 1 && (a.Wout % 16 != 0 || a.Hout % 8 != 0) &&
+        a.Hout * a.Wout >= 96 && a.Hin == a.Hout && a.Win == a.Wout && a.Hy == a.Hout && a.Wy == a.Wout &&
+        JH_ENV_KNOB("JH_CONV_K1_FLAT") != 0) {
+      ConvArgs f = a;
+      f.Win = f.Wout = f.Wy = a.Hout * a.Wout;
+      f.Hin = f.Hout = f.Hy = 1;
+      return conv_launch_2d_k1_flat(f, nr, budget, s);
+    }
     if (d.k == 1 && d.stride == 1) return conv_launch_2d_k1(a, nr, small, budget, s);
     if (d.k == 2 && d.stride == 1) return conv_launch_2d_k2(a, nr, small, budget, s);
+    // (a function of the layer's shape only, like every tile choice: JH_CONV_W20=0 switches it off)
+    if (d.k == 3 && d.stride == 1 && d.ostride == 1 && a.Wout > 16 && a.Wout <= 20 && a.Hout <= 22 &&
+        JH_ENV_KNOB("JH_CONV_W20") != 0)
+      return conv_launch_2d_k3_w20(a, nr, std::max(budget, (size_t)64 * 1024), s);
     if (d.k == 3 && d.stride <= 2) return conv_launch_2d_k3(a, d.stride, nr, small, budget, s);
     if (d.k == 5 && d.stride <= 2) return conv_launch_2d_k5(a, d.stride, nr, small, budget, s);
   } else {

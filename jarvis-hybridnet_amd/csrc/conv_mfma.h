@@ -40,7 +40,9 @@ struct ConvGeom {
   static constexpr int TM = TZ * TY * TX;
   static constexpr int MR = TM / 64;          // 16-pixel blocks per wave (4 waves)
   static constexpr int SPAD = (STRIDE == 1) ? 4 : 2;
-  static_assert(TM % 64 == 0, "tile must be a multiple of 64 pixels");
+  // TM is a multiple of 64, or -- the whole-image geometries, e.g. 23 x 20 for images up to 22 x 20 -- the pixel slots
+  // past 64 MR are never computed: the launcher uses such a geometry only where they lie outside the output
+  static_assert(TM % 64 == 0 || (TZ == 1 && TM / 64 >= 1), "tile must cover at least 64 pixels");
   static size_t lds_bytes(int kc) { return (size_t)NPIX * (kc + SPAD) * sizeof(float); }
 };
 
@@ -784,8 +786,10 @@ bool deconv4_eligible(int cin_p, int cout_p16);
 // per-translation-unit entry points (one .hip file per kernel family so the
 // instantiations compile in parallel)
 int conv_launch_2d_k1(const ConvArgs& a, int nr, int small, size_t budget, hipStream_t s);
+int conv_launch_2d_k1_flat(const ConvArgs& a, int nr, size_t budget, hipStream_t s);
 int conv_launch_2d_k2(const ConvArgs& a, int nr, int small, size_t budget, hipStream_t s);
 int conv_launch_2d_k3(const ConvArgs& a, int stride, int nr, int small, size_t budget, hipStream_t s);
+int conv_launch_2d_k3_w20(const ConvArgs& a, int nr, size_t budget, hipStream_t s);
 int conv_launch_2d_k5(const ConvArgs& a, int stride, int nr, int small, size_t budget, hipStream_t s);
 int conv_launch_2d_big(const ConvArgs& a, int k, int stride, int nr, size_t budget, hipStream_t s);
 int conv_launch_3d_k1(const ConvArgs& a, int nr, int small, size_t budget, hipStream_t s);

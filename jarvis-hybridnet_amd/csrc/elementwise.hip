@@ -306,7 +306,10 @@ __global__ __launch_bounds__(256) void depthwise_lds_kernel(
   const int c4 = tid & (QN - 1);                   // fixed channel quad of this thread
   const bool active = c4 < q;
   __syncthreads();
-  double d1[4] = {0.0, 0.0, 0.0, 0.0}, d2[4] = {0.0, 0.0, 0.0, 0.0};     // fp64 partials (jh_common.h: stat_acc)
+  // statistics partials: packed fp32 sums of (v - pivot), (v - pivot)^2 around the thread's first output, un-shifted in
+  // fp64 at the end (jh_common.h, stat_add(double); conv_mfma.h's epilogue does the same)
+  df2 s1l = (df2){0.f, 0.f}, s1h = s1l, s2l = s1l, s2h = s1l, pvl = s1l, pvh = s1l;
+  int cnt = 0;
   static_assert(!POOL || SL == 64, "the fused pooled sums keep a thread's one strip in registers");
   df2 al[4], ah[4];                                // packed fp32 FMAs: two channels per instruction
   unsigned okm = 0;                                // (POOL) which of the strip's four pixels are inside the image
@@ -342,8 +345,11 @@ __global__ __launch_bounds__(256) void depthwise_lds_kernel(
         if (oy < H && ox < W) {
           *reinterpret_cast<df4*>(y + (((size_t)n * H + oy) * W + ox) * Cp + c0 + c4 * 4) =
               (df4){al[o][0], al[o][1], ah[o][0], ah[o][1]};
-          stat_acc(d1[0], d2[0], al[o][0]); stat_acc(d1[1], d2[1], al[o][1]);
-          stat_acc(d1[2], d2[2], ah[o][0]); stat_acc(d1[3], d2[3], ah[o][1]);
+          if (cnt == 0) { pvl = al[o]; pvh = ah[o]; }
+          const df2 dl = al[o] - pvl, dh = ah[o] - pvh;
+          s1l += dl; s1h += dh;
+          s2l = __builtin_elementwise_fma(dl, dl, s2l); s2h = __builtin_elementwise_fma(dh, dh, s2h);
+          ++cnt;
           okm |= 1u << o;
         }
       }
@@ -354,8 +360,17 @@ __global__ __launch_bounds__(256) void depthwise_lds_kernel(
     // [SL rows][QN quads][2][4] doubles; fixed-order two-level sum (8 threads x SL / 8 rows, then 8 partials)
     double* smd = reinterpret_cast<double*>(sm);
     double* p = smd + ((size_t)(tid >> QS) * QN + c4) * 8;
+    {
+      const float pv[4] = {pvl[0], pvl[1], pvh[0], pvh[1]}, t1[4] = {s1l[0], s1l[1], s1h[0], s1h[1]},
+                  t2[4] = {s2l[0], s2l[1], s2h[0], s2h[1]};
+      const double nd = (double)cnt;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { p[k] = d1[k]; p[4 + k] = d2[k]; }
+      for (int k = 0; k < 4; ++k) {
+        const double md = (double)pv[k], a1 = (double)t1[k];
+        p[k] = fma(nd, md, a1);
+        p[4 + k] = fma(md, fma(nd, md, 2.0 * a1), (double)t2[k]);
+      }
+    }
     double* red2 = smd + SL * QN * 8;              // [QN * 8 values][8 parts]
     __syncthreads();
     for (int i = tid; i < q * 8 * 8; i += 256) {

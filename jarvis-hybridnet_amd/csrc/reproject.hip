@@ -774,12 +774,26 @@ int launch_reproject(const float* cam, const float* intr, const float* dist, con
     switch (Q) {
       case 2: return launch_cube<2, 8, 1024>(ca, T, s);
       case 4: return launch_cube<4, 8, 512>(ca, T, s);
-      case 6: return JH_ENV_KNOB("JH_REPRO_NT") == 512 ? launch_cube<6, 8, 512>(ca, T, s)
-                                                        : launch_cube<6, 8, 1024>(ca, T, s);
+      case 6:
+        if (JH_ENV_KNOB("JH_REPRO_CI4") > 0) {
+          // experiment (round 6): 4-voxel-thick cubes on 512 threads with HALF the patch buffers -- two workgroups per
+          // CU that cover each other's per-camera barriers; boxes over the limit take the per-lane global path
+          ca.patch_bytes = ((80 * 1024 - kCubePatchOff(4)) / 2) & ~1023;
+          ca.patch_limit = std::min(ca.patch_limit, ca.patch_bytes);
+          return launch_cube<6, 4, 512>(ca, T, s);
+        }
+        return JH_ENV_KNOB("JH_REPRO_NT") == 512 ? launch_cube<6, 8, 512>(ca, T, s)
+                                                 : launch_cube<6, 8, 1024>(ca, T, s);
       // 32 channels: 4-voxel-thick cubes, one voxel per lane (configs[4]: 1.37 against 1.48 ms per 8 frames
       // for the 8-thick cube on 512 threads, 1.52 for the voxel-row kernel)
-      case 8: return JH_ENV_KNOB("JH_REPRO_Q8") == 0 ? launch_cube<8, 8, 512>(ca, T, s)
-                                                     : launch_cube<8, 4, 1024>(ca, T, s);
+      case 8:
+        if (JH_ENV_KNOB("JH_REPRO_CI4") > 0) {       // (the same experiment at 32 channels: configs[4])
+          ca.patch_bytes = ((80 * 1024 - kCubePatchOff(4)) / 2) & ~1023;
+          ca.patch_limit = std::min(ca.patch_limit, ca.patch_bytes);
+          return launch_cube<8, 4, 512>(ca, T, s);
+        }
+        return JH_ENV_KNOB("JH_REPRO_Q8") == 0 ? launch_cube<8, 8, 512>(ca, T, s)
+                                               : launch_cube<8, 4, 1024>(ca, T, s);
       default: break;
     }
   }

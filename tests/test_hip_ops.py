@@ -46,6 +46,13 @@ CONV2D = [  # k, stride, cin, cout, H, W, bias, norm_act
     (5, 2, 16, 96, 32, 32, False, -1), (5, 1, 40, 240, 12, 12, False, 2), (1, 1, 240, 56, 16, 16, False, 0),
     (1, 1, 56, 56, 4, 4, True, 0), (1, 1, 24, 56, 8, 8, True, -1), (3, 1, 40, 240, 16, 16, False, -1),
     (3, 2, 24, 144, 32, 32, False, 2), (1, 1, 56, 336, 16, 16, False, -1), (1, 1, 336, 56, 6, 10, False, 0),
+    # pointwise layers on images that do not tile into 8 x 16: flattened to one row of H * W pixels, 1 x 128 tiles
+    # (csrc/conv_host.hip) -- the 20 x 20 / 10 x 10 / 40 x 40 levels of the reference's default 320-pixel geometry
+    (1, 1, 480, 80, 20, 20, False, 0), (1, 1, 112, 672, 20, 20, False, 2), (1, 1, 40, 88, 40, 40, True, 0),
+    (1, 1, 88, 88, 10, 10, True, -1), (1, 1, 24, 88, 12, 24, True, 0), (1, 1, 16, 8, 10, 13, False, 2),
+    # 3 x 3 stride-1 layers on images 17..20 wide, at most 22 high: one whole-image tile of 23 x 20 pixel slots
+    (3, 1, 80, 480, 20, 20, False, 2), (3, 1, 24, 40, 22, 17, True, -1), (3, 1, 16, 16, 9, 20, False, 0),
+    (3, 1, 40, 56, 23, 20, False, 0),     # (23 rows: past the whole-image tile's reach -> the 8 x 16 tiles)
 ]
 
 
