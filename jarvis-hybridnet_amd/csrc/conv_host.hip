@@ -204,6 +204,7 @@ int launch_conv(const ConvDesc& d, const ConvWeights& w, const Act& x, const Act
   }
   JH_REQUIRE(!a.paired || (a.paired == 2 && d.nd == 3 && d.k == 3 && d.stride == 2),
              "paired weight layout without a kernel that reads it");
+  if (conv_pw_direct_eligible(d, a)) return launch_conv_pw_direct(a, s);
   if (d.nd == 2) {
     const int small = (a.Wout <= 8) ? 1 : 0;
     // 16 x 16 tiles for high-resolution layers with few input channels

@@ -779,6 +779,10 @@ int launch_conv_geom(const ConvArgs& a, int nr, size_t lds_budget, hipStream_t s
   JH_REQUIRE(false, "bad (NR, KC8)");
 }
 
+// few-channel pointwise layers straight from registers (csrc/conv_pw_direct.hip)
+bool conv_pw_direct_eligible(const ConvDesc& d, const ConvArgs& a);
+int launch_conv_pw_direct(const ConvArgs& a, hipStream_t s);
+
 // ConvTranspose2d k4 s2 p1 with the four parities in one workgroup (csrc/deconv4.hip); -1: not its layer
 int launch_deconv4_fused(const ConvArgs& a, hipStream_t s);
 bool deconv4_eligible(int cin_p, int cout_p16);

@@ -53,6 +53,10 @@ CONV2D = [  # k, stride, cin, cout, H, W, bias, norm_act
     # 3 x 3 stride-1 layers on images 17..20 wide, at most 22 high: one whole-image tile of 23 x 20 pixel slots
     (3, 1, 80, 480, 20, 20, False, 2), (3, 1, 24, 40, 22, 17, True, -1), (3, 1, 16, 16, 9, 20, False, 0),
     (3, 1, 40, 56, 23, 20, False, 0),     # (23 rows: past the whole-image tile's reach -> the 8 x 16 tiles)
+    # few-channel pointwise layers straight from registers (csrc/conv_pw_direct.hip): K <= 48, 1 / 4 / 6 column blocks
+    (1, 1, 16, 8, 64, 64, False, 2), (1, 1, 48, 16, 32, 32, False, 0), (1, 1, 16, 56, 32, 32, True, 0),
+    (1, 1, 24, 56, 16, 16, True, -1), (1, 1, 24, 88, 16, 32, True, 0), (1, 1, 40, 88, 20, 20, True, 0),
+    (1, 1, 32, 16, 64, 32, False, 2), (1, 1, 8, 8, 40, 40, True, 2),
 ]
 
 
