@@ -112,6 +112,25 @@ def executed_flops(name, flops):
     return flops * pad * (12.0 / 27.0 if "wino" in name else 1.0)
 
 
+def price(name, flops, nbytes, s):
+    """Roofline row of one launch (or of all launches of one kernel name): a convolution is bound by whichever floor is
+    HIGHER -- the matrix cores (executed FLOPs / peak) or HBM (algorithmic bytes: one read of the input, one write of the
+    output, the weights / 8 TB/s); the few-channel 1x1 and stem-side layers are HBM-bound, pricing them against the matrix
+    peak hid their head-room.  Both fractions are kept; `frac` is the binding one.  Everything else: HBM."""
+    if flops > 0 and kernel_family(name) == "mfma":
+        ex = executed_flops(name, flops)
+        peak = PEAK_BF16_MFMA_TFLOPS if "bf16x3" in name else PEAK_F32_MFMA_TFLOPS
+        t_mfma, t_hbm = ex / (peak * 1e12), nbytes / (PEAK_HBM_GBS * 1e9)
+        fm, fh = t_mfma / s, t_hbm / s
+        if t_hbm > t_mfma:
+            return dict(kernel=name, bound="hbm", achieved=nbytes / s / 1e9, peak=PEAK_HBM_GBS, unit="GB/s",
+                        frac=fh, frac_mfma=fm, frac_hbm=fh)
+        return dict(kernel=name, bound="mfma", achieved=ex / s / 1e12, peak=peak, unit="TFLOP/s", frac=fm,
+                    frac_mfma=fm, frac_hbm=fh, algorithmic_equiv=flops / s / 1e12)
+    return dict(kernel=name, bound="hbm", achieved=nbytes / s / 1e9, peak=PEAK_HBM_GBS, unit="GB/s",
+                frac=nbytes / s / 1e9 / PEAK_HBM_GBS)
+
+
 def kernel_table(recs, passes, top=10):
     """Per-kernel roofline rows from HIP-event records of `passes` profiled passes:
     median duration per launch position, summed per kernel name."""
@@ -129,24 +148,7 @@ def kernel_table(recs, passes, top=10):
     out = []
     for name, r in sorted(rows.items(), key=lambda kv: -kv[1]["ms"]):
         s = r["ms"] * 1e-3
-        if r["flops"] > 0 and kernel_family(name) == "mfma":
-            # a convolution is bound by whichever floor is HIGHER: the matrix cores (executed FLOPs / peak) or HBM
-            # (algorithmic bytes: one read of the input, one write of the output, the weights / 8 TB/s) -- the
-            # few-channel 1x1 and stem-side layers are HBM-bound, pricing them against the matrix peak hid their
-            # head-room.  Both fractions are printed; `frac` is the binding one.
-            ex = executed_flops(name, r["flops"])
-            peak = PEAK_BF16_MFMA_TFLOPS if "bf16x3" in name else PEAK_F32_MFMA_TFLOPS
-            t_mfma, t_hbm = ex / (peak * 1e12), r["bytes"] / (PEAK_HBM_GBS * 1e9)
-            fm, fh = t_mfma / s, t_hbm / s
-            if t_hbm > t_mfma:
-                row = dict(kernel=name, bound="hbm", achieved=r["bytes"] / s / 1e9, peak=PEAK_HBM_GBS, unit="GB/s",
-                           frac=fh, frac_mfma=fm, frac_hbm=fh)
-            else:
-                row = dict(kernel=name, bound="mfma", achieved=ex / s / 1e12, peak=peak, unit="TFLOP/s", frac=fm,
-                           frac_mfma=fm, frac_hbm=fh, algorithmic_equiv=r["flops"] / s / 1e12)
-        else:
-            row = dict(kernel=name, bound="hbm", achieved=r["bytes"] / s / 1e9, peak=PEAK_HBM_GBS,
-                       unit="GB/s", frac=r["bytes"] / s / 1e9 / PEAK_HBM_GBS)
+        row = price(name, r["flops"], r["bytes"], s)
         if name.startswith("stem_conv"):
             # which floor `algorithmic_bytes` is for the fused resize / crop + stem: the bytes of the taps themselves.  The
             # no-antialias 1280 -> 256 resize touches 1 pixel in 5 on 2 rows in 4, and HBM delivers 64-byte sectors: the

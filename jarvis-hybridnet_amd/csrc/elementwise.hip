@@ -257,11 +257,14 @@ int launch_se_gate(const double* pool, int N, int C, int Cp, int S, float inv_hw
 // own (complete) statistics with norm_apply's expressions, then sum_p SiLU((y - mean) rstd) per channel from the
 // outputs still in registers -> `pool`.  The second pass over the 6 x expanded tensor (norm_apply in pooled-sums-only
 // form, efficientnet.py:102-106) is not launched for these blocks.
-template <int K, int CC, bool POOL = false>
+// TT: tile side.  16, or 20 for images 17 .. 20 pixels wide / high (the stride-16 level of the reference's DEFAULT
+// 320-pixel geometry: 20 x 20 filled 39 % of its four 16 x 16 tiles and, not being one tile, could not fuse the pooled sums)
+template <int K, int CC, bool POOL = false, int TT = 16>
 __global__ __launch_bounds__(256) void depthwise_lds_kernel(
     const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
     double* __restrict__ stats, int H, int W, int Cp, double* __restrict__ pool = nullptr) {
-  constexpr int T = 16, HT = T + K - 1, SP = CC + 4;
+  constexpr int T = TT, HT = T + K - 1, SP = CC + 4;
+  static_assert(T % 4 == 0, "tiles are made of 4-pixel strips");
   constexpr int QN = CC / 4, SL = 256 / QN;         // channel quads of a chunk, pixel slots (threads per quad)
   constexpr int QS = QN == 8 ? 3 : 2;               // log2(QN)
   static_assert(CC == 32 || CC == 16, "channel chunk");
@@ -310,14 +313,21 @@ __global__ __launch_bounds__(256) void depthwise_lds_kernel(
   // fp64 at the end (jh_common.h, stat_add(double); conv_mfma.h's epilogue does the same)
   df2 s1l = (df2){0.f, 0.f}, s1h = s1l, s2l = s1l, s2h = s1l, pvl = s1l, pvh = s1l;
   int cnt = 0;
-  static_assert(!POOL || SL == 64, "the fused pooled sums keep a thread's one strip in registers");
-  df2 al[4], ah[4];                                // packed fp32 FMAs: two channels per instruction
-  unsigned okm = 0;                                // (POOL) which of the strip's four pixels are inside the image
+  // strips of 4 pixels per tile row / per tile, strips per thread; the fused pooled sums keep a thread's strips in registers
+  constexpr int SPR = T / 4, NSTR = T * SPR, NJ = (NSTR + SL - 1) / SL, NK = POOL ? NJ : 1, UNR = POOL ? NJ : 1;
+  static_assert(!POOL || NJ <= 2, "registers for the strips of a thread");
+  df2 alk[NK][4], ahk[NK][4];                      // packed fp32 FMAs: two channels per instruction
+  unsigned okmk[NK];                               // (POOL) which of a strip's four pixels are inside the image
+#pragma unroll
+  for (int jj = 0; jj < NK; ++jj) okmk[jj] = 0;
   if (active) {
-#pragma unroll 1
-    for (int j = 0; j < 64 / SL; ++j) {
-      const int g = (tid >> QS) + SL * j;          // 64 strips: 16 rows x 4 strips of 4 pixels
-      const int ty = g >> 2, tx0 = (g & 3) * 4;
+#pragma unroll UNR
+    for (int j = 0; j < NJ; ++j) {
+      const int g = (tid >> QS) + SL * j;          // strip g: row g / SPR, pixels 4 (g % SPR) .. + 3
+      if (g >= NSTR) break;
+      df2 (&al)[4] = alk[POOL ? j : 0], (&ah)[4] = ahk[POOL ? j : 0];
+      unsigned& okm = okmk[POOL ? j : 0];
+      const int ty = g / SPR, tx0 = (g % SPR) * 4;
 #pragma unroll
       for (int o = 0; o < 4; ++o) { al[o] = (df2){0.f, 0.f}; ah[o] = al[o]; }
 #pragma unroll 1
@@ -412,13 +422,15 @@ __global__ __launch_bounds__(256) void depthwise_lds_kernel(
         const df4 mean = *reinterpret_cast<const df4*>(mr + c4 * 4);
         const df4 rstd = *reinterpret_cast<const df4*>(mr + CC + c4 * 4);
 #pragma unroll
-        for (int o = 0; o < 4; ++o)
-          if (okm >> o & 1) {
-            ps[0] += silu_fast((al[o][0] - mean[0]) * rstd[0]);
-            ps[1] += silu_fast((al[o][1] - mean[1]) * rstd[1]);
-            ps[2] += silu_fast((ah[o][0] - mean[2]) * rstd[2]);
-            ps[3] += silu_fast((ah[o][1] - mean[3]) * rstd[3]);
-          }
+        for (int jj = 0; jj < NK; ++jj)
+#pragma unroll
+          for (int o = 0; o < 4; ++o)
+            if (okmk[jj] >> o & 1) {
+              ps[0] += silu_fast((alk[jj][o][0] - mean[0]) * rstd[0]);
+              ps[1] += silu_fast((alk[jj][o][1] - mean[1]) * rstd[1]);
+              ps[2] += silu_fast((ahk[jj][o][0] - mean[2]) * rstd[2]);
+              ps[3] += silu_fast((ahk[jj][o][1] - mean[3]) * rstd[3]);
+            }
       }
       __syncthreads();                             // (mr has been read; the reduce below reuses the front of sm)
       reinterpret_cast<df4*>(sm)[(size_t)(tid >> QS) * QN + c4] = ps;        // [SL rows][QN quads][4]
@@ -441,37 +453,43 @@ __global__ __launch_bounds__(256) void depthwise_lds_kernel(
   }
 }
 
-bool depthwise_can_pool(int H, int W) { return H <= 16 && W <= 16; }
+bool depthwise_can_pool(int H, int W) { return H <= 20 && W <= 20; }
 
 int launch_depthwise(const Act& x, const float* w, int k, float* y, double* stats, hipStream_t s, double* pool) {
   JH_REQUIRE(x.D == 1, "depthwise is 2D only");
   JH_REQUIRE(k == 3 || k == 5, "depthwise kernel size must be 3 or 5");
-  const int tiles = ((x.H + 15) / 16) * ((x.W + 15) / 16);
+  // tile side: a function of the image only (16, or 20 for images 17 .. 20 pixels wide / high: one tile instead of four)
+  const int tt = (std::max(x.H, x.W) > 16 && std::max(x.H, x.W) <= 20 && JH_ENV_KNOB("JH_DW_T20") != 0) ? 20 : 16;
+  const int tiles = ((x.H + tt - 1) / tt) * ((x.W + tt - 1) / tt);
   if (pool) {
     // fused squeeze-excite pooled sums: one tile per image, channel chunk 16 (the form does not depend on the batch)
-    JH_REQUIRE(depthwise_can_pool(x.H, x.W) && stats, "fused depthwise pooled sums need a one-tile image and statistics");
+    JH_REQUIRE(depthwise_can_pool(x.H, x.W) && tiles == 1 && stats,
+               "fused depthwise pooled sums need a one-tile image and statistics");
     dim3 grid(1, (x.Cp + 15) / 16, x.N);
-    const int ht = 16 + k - 1;
+    const int ht = tt + k - 1;
     size_t lds = (size_t)(ht * ht * (16 + 4) + k * k * 16) * sizeof(float);
     const size_t red = (size_t)(64 * 4 * 8 + 4 * 8 * 8 + 4 * 8) * sizeof(double) + 2 * 16 * sizeof(float);
     if (lds < red) lds = red;
-    if (k == 3) hipLaunchKernelGGL((depthwise_lds_kernel<3, 16, true>), grid, dim3(256), lds, s, x.p, w, y, stats, x.H, x.W, x.Cp, pool);
-    else hipLaunchKernelGGL((depthwise_lds_kernel<5, 16, true>), grid, dim3(256), lds, s, x.p, w, y, stats, x.H, x.W, x.Cp, pool);
+#define JH_DWP(K, TTV) hipLaunchKernelGGL((depthwise_lds_kernel<K, 16, true, TTV>), grid, dim3(256), lds, s, x.p, w, y, stats, x.H, x.W, x.Cp, pool)
+    if (k == 3) { if (tt == 20) JH_DWP(3, 20); else JH_DWP(3, 16); }
+    else { if (tt == 20) JH_DWP(5, 20); else JH_DWP(5, 16); }
+#undef JH_DWP
     JH_CHECK_HIP(hipGetLastError());
     return 0;
   }
   // Channel chunk per workgroup: 16 (33.6 KB of LDS at k = 5: four workgroups per CU) unless JH_DW_CC=32 (60.8 KB,
   // two per CU: the round-2 form).  The kernel is latency-bound; the chunk is part of no sum (statistics are
   // per channel), so the choice does not depend on anything but the knob.
-  const int cc = JH_ENV_KNOB("JH_DW_CC") == 32 ? 32 : 16;
+  const int cc = (JH_ENV_KNOB("JH_DW_CC") == 32 && tt == 16) ? 32 : 16;
   dim3 grid(tiles, (x.Cp + cc - 1) / cc, x.N);
-  const int ht = 16 + k - 1;
+  const int ht = tt + k - 1;
   size_t lds = (size_t)(ht * ht * (cc + 4) + k * k * cc) * sizeof(float);
   const size_t red = (size_t)((256 / (cc / 4)) * (cc / 4) * 8 + (cc / 4) * 8 * 8) * sizeof(double);
   if (lds < red) lds = red;
-#define JH_DW(K, CC) hipLaunchKernelGGL((depthwise_lds_kernel<K, CC>), grid, dim3(256), lds, s, x.p, w, y, stats, x.H, x.W, x.Cp)
-  if (k == 3) { if (cc == 32) JH_DW(3, 32); else JH_DW(3, 16); }
-  else { if (cc == 32) JH_DW(5, 32); else JH_DW(5, 16); }
+#define JH_DW(K, CC, TTV) hipLaunchKernelGGL((depthwise_lds_kernel<K, CC, false, TTV>), grid, dim3(256), lds, s, x.p, w, y, stats, x.H, x.W, x.Cp)
+  if (tt == 20) { if (k == 3) JH_DW(3, 16, 20); else JH_DW(5, 16, 20); }
+  else if (k == 3) { if (cc == 32) JH_DW(3, 32, 16); else JH_DW(3, 16, 16); }
+  else { if (cc == 32) JH_DW(5, 32, 16); else JH_DW(5, 16, 16); }
 #undef JH_DW
   JH_CHECK_HIP(hipGetLastError());
   return 0;

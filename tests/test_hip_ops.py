@@ -159,7 +159,8 @@ def test_deconv3d_k2s2():
 
 
 @pytest.mark.parametrize("k,c,H,W,norm_act", [(3, 56, 32, 32, -1), (5, 240, 16, 16, 2), (3, 88, 8, 8, -1),
-                                              (5, 336, 12, 20, 2)])
+                                              (5, 336, 12, 20, 2), (5, 480, 20, 20, 2), (3, 88, 18, 20, -1),
+                                              (5, 96, 24, 20, 2)])
 def test_depthwise(k, c, H, W, norm_act):
     from jarvis_hybridnet_amd import _native as N
     g = torch.Generator().manual_seed(k + c)
@@ -177,7 +178,8 @@ def test_depthwise(k, c, H, W, norm_act):
     assert e < 2e-5 * (10 if norm_act >= 0 else 1)
 
 
-@pytest.mark.parametrize("k,c,H,W", [(5, 240, 16, 16), (5, 672, 16, 16), (3, 88, 8, 8), (5, 336, 12, 14), (5, 528, 16, 16)])
+@pytest.mark.parametrize("k,c,H,W", [(5, 240, 16, 16), (5, 672, 16, 16), (3, 88, 8, 8), (5, 336, 12, 14), (5, 528, 16, 16),
+                                     (5, 480, 20, 20), (3, 96, 17, 19), (5, 672, 20, 18)])   # (17 .. 20: the 20 x 20 tile)
 def test_depthwise_fused_se_pool(k, c, H, W):
     """One-tile images: the depthwise launch also delivers sum_p SiLU(InstanceNorm(y)) per (image, channel) -- the
     squeeze-excite pooling of MBConvBlock.forward (efficientnet.py:100-107) without a second pass over y."""

@@ -42,12 +42,8 @@ rows = []
 for i in range(n):
     name, _, fl, by = recs[0][i]
     ms = sorted(recs[p][i][1] for p in range(a.passes))[a.passes // 2]
-    fam = bench.kernel_family(name)
-    if fam == "mfma" and fl > 0:
-        frac = bench.executed_flops(name, fl) / (ms * 1e-3) / 1e12 / bench.PEAK_F32_MFMA_TFLOPS
-    else:
-        frac = by / (ms * 1e-3) / 1e9 / bench.PEAK_HBM_GBS
-    rows.append((i, name, ms, fam, frac, fl, by))
+    pr = bench.price(name, fl, by, ms * 1e-3)        # the binding roofline of the launch (bench.py)
+    rows.append((i, name, ms, pr["bound"], pr["frac"], fl, by))
 total = sum(r[2] for r in rows)
 lines = ["# %s %s T=%d: %d launches, %.3f ms of kernel time" % (a.config, a.model_size, T, n, total),
          "idx\tkernel\tms\tbound\tfrac\tcum_ms\talg_gflop\talg_mb"]
