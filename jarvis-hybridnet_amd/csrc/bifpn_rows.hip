@@ -416,7 +416,15 @@ static int launch_rows_rc(const NodeArgs& a, hipStream_t s) {
   //  chip better -- measured at 384 images: 32-row segments at the 32-pixel levels 0.155 -> 0.140 / 0.188 -> 0.167 ms,
   //  the three-input head at 64 pixels 0.445 -> 0.397 with 32 rows instead of 16; the 16-pixel levels keep 8 rows: 0.051
   //  against 0.078 with one segment per image)
-  if (RC == 88 && JH_ENV_KNOB("JH_NODE_SEG") <= 0 && a.H >= 32) seg_rows = 32;
+  if (RC == 88 && JH_ENV_KNOB("JH_NODE_SEG") <= 0 && a.H >= 32) {
+    seg_rows = 32;
+    // (the pairs of a workgroup must walk the same number of rows: a level that is no multiple of 32 -- 80 x 80 in the
+    //  reference's DEFAULT 320-pixel geometry -- takes its largest even divisor up to 40 that leaves two segments; with
+    //  32 it fell back to the one-wave form at 1.4x the time per pixel)
+    if (a.H % 32 != 0)
+      for (int d = std::min(40, a.H / 2) & ~1; d >= 8; d -= 2)
+        if (a.H % d == 0) { seg_rows = d; break; }
+  }
   seg_rows = (seg_rows + 1) & ~1;                // (even: the kernel's row loop is unrolled by two on row parity)
   if (seg_rows > a.H) seg_rows = a.H;
   const int segs = (a.H + seg_rows - 1) / seg_rows;
