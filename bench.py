@@ -71,7 +71,7 @@ CONFIGS = {
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_16x16x32_bf16 / 32x32x16, dense
 PEAK_HBM_GBS = 8000.0
-PMC_TRAFFIC = os.path.join("profiles", "r05_pmc_traffic.json")
+PMC_TRAFFIC = os.path.join("profiles", "r06_pmc_traffic.json")
 
 
 def usable_cores():

@@ -3,8 +3,8 @@
 # lines of configs[2] (small / medium / large), configs[1]'s geometry, configs[4] and the shipped 72^3 geometry, the full
 # per-kernel table, per-launch tables, and the rocprofv3 kernel-trace summary of a single-stream run.  Everything lands
 # in gpurun_out/<tag>_*; copy what is to be judged into profiles/.
-#   bash tools/final_profiles.sh r05
-tag=${1:-r05}
+#   bash tools/final_profiles.sh r06
+tag=${1:-r06}
 root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$root"
 mkdir -p gpurun_out
@@ -16,6 +16,9 @@ python3 bench.py --config cfg2 --no-secondary > gpurun_out/${tag}_bench_cfg2_3x3
 python3 bench.py --config ex72 --no-secondary --no-cpu-baseline > gpurun_out/${tag}_bench_ex72_3x24.json 2> /dev/null
 python3 bench.py --model-size medium --no-secondary --no-cpu-baseline --no-uint8 --no-reduced-precision > gpurun_out/${tag}_bench_cfg3_medium_3x32.json 2> /dev/null
 python3 bench.py --model-size large --no-secondary --no-cpu-baseline --no-uint8 --no-reduced-precision > gpurun_out/${tag}_bench_cfg3_large_3x32.json 2> /dev/null
+# the reference's DEFAULT configuration (medium / medium, 320 / 320, 72^3): its own bench line, with the CPU baseline
+python3 bench.py --config def320 --no-secondary > gpurun_out/${tag}_bench_def320_3x16.json 2> /dev/null
+python3 tools/launch_table.py --config def320 --out gpurun_out/${tag}_launches_def320_medium.tsv > /dev/null 2>&1
 for m in small medium large; do python3 tools/launch_table.py --model-size $m --out gpurun_out/${tag}_launches_cfg3_$m.tsv > /dev/null 2>&1; done
 python3 tools/launch_table.py --config ex72 --out gpurun_out/${tag}_launches_ex72_small.tsv > /dev/null 2>&1
 python3 tools/launch_table.py --config cfg5 --out gpurun_out/${tag}_launches_cfg5_small.tsv > /dev/null 2>&1

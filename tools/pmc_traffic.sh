@@ -5,7 +5,7 @@
 # csrc/ (bench.py reports `traffic` only for a matching tree).  Run on the GPU box:
 #   tools/pmc_traffic.sh r04
 set -e
-round=${1:-r05}
+round=${1:-r06}
 root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$root"
 T=32
