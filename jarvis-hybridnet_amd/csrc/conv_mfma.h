@@ -112,6 +112,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[MR][NR], const Epilog
     double s1 = 0.0, s2 = 0.0;
     if (e.stats) {
       typedef float sf2 __attribute__((ext_vector_type(2)));
+      // (any finite value works as the pivot; pixel slots outside the output hold sums over the zero-filled halo)
       const float m = acc[0][nr][0] + bv;
       const sf2 m2 = (sf2){m, m};
       sf2 t1a = (sf2){0.f, 0.f}, t1b = t1a, t2a = t1a, t2b = t1a;
@@ -781,6 +782,7 @@ int launch_conv_geom(const ConvArgs& a, int nr, size_t lds_budget, hipStream_t s
 
 // few-channel pointwise layers straight from registers (csrc/conv_pw_direct.hip)
 bool conv_pw_direct_eligible(const ConvDesc& d, const ConvArgs& a);
+bool conv_pw_direct_shape_ok(int cin_p, int cout_p16, int pixels);
 int launch_conv_pw_direct(const ConvArgs& a, hipStream_t s);
 
 // ConvTranspose2d k4 s2 p1 with the four parities in one workgroup (csrc/deconv4.hip); -1: not its layer

@@ -206,6 +206,17 @@ __global__ __launch_bounds__(256) void conv_pw_direct_kernel(const ConvArgs a, i
 
 // Layers this kernel takes: plain 1 x 1 convolutions with at most 48 input channels and 1 or 4 column blocks of output
 // channels on images of a multiple of 16 pixels, gate (if any) given as a tensor.  JH_CONV_PW_DIRECT=0: never.
+// The shape part of the decision, for the plan builder: a project convolution this kernel takes must get its squeeze-
+// excite gate as a TENSOR whatever the batch size (the in-prologue recipe of the general kernel is chosen by the number
+// of images, and the two kernels group the statistics' partial sums differently: the choice of kernel must not depend
+// on the batch).
+bool conv_pw_direct_shape_ok(int cin_p, int cout_p16, int pixels) {
+  if (JH_ENV_KNOB("JH_CONV_PW_DIRECT") == 0) return false;
+  const int nb = cout_p16 / 16;
+  if (cin_p > 48 || (nb != 1 && nb != 4)) return false;
+  return pixels % 16 == 0 && pixels >= (nb == 1 ? 1024 : 4096);
+}
+
 bool conv_pw_direct_eligible(const ConvDesc& d, const ConvArgs& a) {
   if (JH_ENV_KNOB("JH_CONV_PW_DIRECT") == 0) return false;
   if (d.nd != 2 || d.k != 1 || d.stride != 1 || d.ostride != 1 || d.nphase != 1 || a.se.pool || a.paired) return false;

@@ -171,6 +171,8 @@ struct InNorm {
   float inv = 0.f;
   int act = 0;
 };
+// which few-channel 1 x 1 layers the direct register kernel takes, by shape (csrc/conv_pw_direct.hip)
+bool conv_pw_direct_shape_ok(int cin_p, int cout_p16, int pixels);
 int launch_conv(const ConvDesc& d, const ConvWeights& w, const Act& x, const Act& y,
                 const float* gate, double* stats, hipStream_t s, const InNorm* in = nullptr,
                 const SeGate* se = nullptr);

@@ -258,6 +258,14 @@ NODE_CASES = [  # (C, Cout, H, W, modes, act, n): the node shapes of the small /
     (160, 160, 24, 24, (0, 1), 2, 512),     # 192-pixel crops: P4 is 24 wide (one full and one half strip)
     (160, 160, 24, 40, (0, 1, 2), 0, 384),  # three strips, the last one half empty; x1 / x2 / x4 inputs
     (56, 56, 4, 4, (0, 0), 2, 3),           # the tile kernel's two-same-input variant (fallback of the above)
+    # 88 channels on level sizes of the reference's DEFAULT 320-pixel geometry (round 6; the stand-alone operator has no
+    # time-batch class, so the ragged levels take the tile kernel here -- the workgroup row form on them is exercised by
+    # the default_medium_320 fixture in its T = 8 class)
+    (88, 88, 40, 40, (0, 1), 2, 20),        # P4 top-down, 2.5 tiles wide
+    (88, 88, 20, 20, (0, 0, 3), 2, 20),     # P5 bottom-up
+    (88, 88, 80, 80, (0, 1), 2, 43),        # P3 top-down: 40-row segments (80 % 32 != 0); 430 items: one-wave form
+    (88, 88, 80, 80, (0, 1), 2, 44),        # ... 440 items = 110 workgroups of four pairs: the pair form
+    (88, 88, 32, 32, (0, 1), 2, 255),       # aligned level, item count no multiple of 4
 ]
 
 

@@ -32,6 +32,7 @@ for s in streams:
         preds.append(p)
 torch.cuda.synchronize()
 bad = 0
+class_bad = 0
 first = None
 strict = os.environ.get("JH_NODE_ROWS") == "0" or T < 8
 for r in range(REPS):
@@ -45,10 +46,14 @@ for r in range(REPS):
             first = (o[0][0].clone(), o[1][0].clone())
             d = float((first[0] - ref[0][0]).abs().max())
             print("soak: batch vs single-frame call: %.3g mm%s" % (d, " (bit-equal required)" if strict else ""))
-            if d > 1e-4 or (strict and not (torch.equal(first[0], ref[0][0]) and torch.equal(first[1], ref[1][0]))):
-                bad += 1
+            # the two time-batch classes agree to 2-6e-5 mm (small, medium), 1.1-1.8e-4 mm (large): the bound the fixture
+            # test holds (tests/test_hip_predictor.py::test_predictor3d_time_batch_8_vs_fixture) -- counted apart from
+            # the bit-equality of the runs
+            if d > 3e-4 or (strict and not (torch.equal(first[0], ref[0][0]) and torch.equal(first[1], ref[1][0]))):
+                class_bad = 1
         for t in range(T):
             if not (torch.equal(o[0][t], first[0]) and torch.equal(o[1][t], first[1])):
                 bad += 1
-print("soak: %d runs x %d streams x %d frames, mismatching frames: %d" % (REPS, STREAMS, T, bad))
-sys.exit(1 if bad else 0)
+print("soak: %d runs x %d streams x %d frames, mismatching frames: %d%s" % (
+    REPS, STREAMS, T, bad, "; batch vs single-frame call OUT OF BOUND" if class_bad else ""))
+sys.exit(1 if bad or class_bad else 0)
