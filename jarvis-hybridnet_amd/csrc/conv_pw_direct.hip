@@ -79,11 +79,39 @@ __global__ __launch_bounds__(256) void conv_pw_direct_kernel(const ConvArgs a, i
         rs4[u] = *reinterpret_cast<const pf4*>(&nrm_s[wave][1][16 * u + 4 * kq]);
       }
   }
-  const bool gated = a.gate != nullptr;
-  if (gated) {
+  const bool gated = a.gate != nullptr || a.se.pool != nullptr;
+  if (a.gate) {
 #pragma unroll
     for (int u = 0; u < KW; ++u)
       if (16 * u + 4 * kq < a.cin_p) g4[u] = *reinterpret_cast<const pf4*>(a.gate + (size_t)n * a.cin_p + 16 * u + 4 * kq);
+  } else if (a.se.pool) {
+    // the squeeze-excite gate of image n from the pooled sums, per wave (C <= 48 channels, S <= 16 hidden units: lane c /
+    // lane j each own one): the arithmetic of se_gate_kernel (elementwise.hip) and of the general kernel's prologue, term
+    // for term -- whichever form the plan picks (by batch size), the gate has the same bits
+    __shared__ float se_s[4][2][64];
+    const int C = a.se.C, S = a.se.S;
+    se_s[wave][0][lane] = lane < C ? (float)(exact_read(a.se.pool + ((size_t)n * a.cin_p + lane) * kLimbs) * (double)a.se.inv_hw) : 0.f;
+    __builtin_amdgcn_wave_barrier();
+    float hid = 0.f;
+    if (lane < S) {
+      float acc = a.se.br[lane];
+      for (int c = 0; c < C; ++c) acc = fmaf(a.se.wr[lane * C + c], se_s[wave][0][c], acc);
+      hid = acc / (1.f + expf(-acc));
+    }
+    se_s[wave][1][lane] = hid;
+    __builtin_amdgcn_wave_barrier();
+    float g = 0.f;
+    if (lane < C) {
+      float acc = a.se.be[lane];
+      for (int j = 0; j < S; ++j) acc = fmaf(a.se.we[lane * S + j], se_s[wave][1][j], acc);
+      g = 1.f / (1.f + expf(-acc));
+    }
+    __builtin_amdgcn_wave_barrier();                // (every lane has read the means before they are overwritten)
+    se_s[wave][0][lane] = g;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int u = 0; u < KW; ++u)
+      if (16 * u + 4 * kq < a.cin_p) g4[u] = *reinterpret_cast<const pf4*>(&se_s[wave][0][16 * u + 4 * kq]);
   }
   const int act = a.in_act;
 
@@ -206,10 +234,9 @@ __global__ __launch_bounds__(256) void conv_pw_direct_kernel(const ConvArgs a, i
 
 // Layers this kernel takes: plain 1 x 1 convolutions with at most 48 input channels and 1 or 4 column blocks of output
 // channels on images of a multiple of 16 pixels, gate (if any) given as a tensor.  JH_CONV_PW_DIRECT=0: never.
-// The shape part of the decision, for the plan builder: a project convolution this kernel takes must get its squeeze-
-// excite gate as a TENSOR whatever the batch size (the in-prologue recipe of the general kernel is chosen by the number
-// of images, and the two kernels group the statistics' partial sums differently: the choice of kernel must not depend
-// on the batch).
+// The shape part of the decision.  Which kernel runs must not depend on the batch (the two kernels group the statistics'
+// partial sums differently): this kernel therefore takes the squeeze-excite gate in BOTH forms the plan uses -- a tensor,
+// or the recipe the general kernel evaluates in its prologue for small batches.
 bool conv_pw_direct_shape_ok(int cin_p, int cout_p16, int pixels) {
   if (JH_ENV_KNOB("JH_CONV_PW_DIRECT") == 0) return false;
   const int nb = cout_p16 / 16;
@@ -219,7 +246,8 @@ bool conv_pw_direct_shape_ok(int cin_p, int cout_p16, int pixels) {
 
 bool conv_pw_direct_eligible(const ConvDesc& d, const ConvArgs& a) {
   if (JH_ENV_KNOB("JH_CONV_PW_DIRECT") == 0) return false;
-  if (d.nd != 2 || d.k != 1 || d.stride != 1 || d.ostride != 1 || d.nphase != 1 || a.se.pool || a.paired) return false;
+  if (d.nd != 2 || d.k != 1 || d.stride != 1 || d.ostride != 1 || d.nphase != 1 || a.paired) return false;
+  if (a.se.pool && (a.se.C > 64 || a.se.S > 64)) return false;
   if (a.cin_p > 48 || a.in_px != a.cin_p) return false;
   const int nb = a.cout_p16 / 16;
   // (six column blocks -- the 88-channel laterals of the medium model -- need 256 registers: one wave per SIMD, measured

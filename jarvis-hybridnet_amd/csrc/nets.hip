@@ -354,10 +354,7 @@ int EffTrackPlan::mbconv(const ParamMap& pm, const std::string& p, int stage, in
   // against 1973-1985 frames/s), so large batches keep the stand-alone se_gate launch.  JH_SE_FUSE=0 / 1
   // forces either form.
   const int se_knob = JH_ENV_KNOB("JH_SE_FUSE");
-  // (... except in front of a project convolution that the direct few-channel kernel takes, csrc/conv_pw_direct.hip: it
-  //  wants the gate as a tensor, and which kernel runs must not depend on the batch)
-  const bool se_fused = (se_knob >= 0 ? se_knob != 0 : raw.N <= 32) &&
-                        !conv_pw_direct_shape_ok(raw.Cp, (cout + 15) / 16 * 16, Ho * Wo);
+  const bool se_fused = se_knob >= 0 ? se_knob != 0 : raw.N <= 32;
   SeGate seg;
   seg.wr = dwr; seg.br = dbr; seg.we = dwe; seg.be = dbe; seg.C = mid; seg.S = squeeze; seg.inv_hw = inv_hw;
   if (!se_fused) {
