@@ -227,8 +227,10 @@ int launch_conv(const ConvDesc& d, const ConvWeights& w, const Act& x, const Act
     if (d.k == 1 && d.stride == 1) return conv_launch_2d_k1(a, nr, small, budget, s);
     if (d.k == 2 && d.stride == 1) return conv_launch_2d_k2(a, nr, small, budget, s);
     // (a function of the layer's shape only, like every tile choice: JH_CONV_W20=0 switches it off)
+    // (time-batch class >= 8 only: one tile per image leaves a 12-image launch with a sixth of the workgroups -- measured
+    //  on one frame set of the default geometry: 80 -> 480 @ 20 94 us against 63)
     if (d.k == 3 && d.stride == 1 && d.ostride == 1 && a.Wout > 16 && a.Wout <= 20 && a.Hout <= 22 &&
-        JH_ENV_KNOB("JH_CONV_W20") != 0)
+        !d.latency_class && JH_ENV_KNOB("JH_CONV_W20") != 0)
       return conv_launch_2d_k3_w20(a, nr, std::max(budget, (size_t)64 * 1024), s);
     if (d.k == 3 && d.stride <= 2) return conv_launch_2d_k3(a, d.stride, nr, small, budget, s);
     if (d.k == 5 && d.stride <= 2) return conv_launch_2d_k5(a, d.stride, nr, small, budget, s);

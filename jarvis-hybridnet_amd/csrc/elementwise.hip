@@ -453,7 +453,9 @@ __global__ __launch_bounds__(256) void depthwise_lds_kernel(
   }
 }
 
-bool depthwise_can_pool(int H, int W) { return H <= 20 && W <= 20; }
+bool depthwise_can_pool(int H, int W) {
+  return (H <= 16 && W <= 16) || (H <= 20 && W <= 20 && JH_ENV_KNOB("JH_DW_T20") != 0);
+}
 
 int launch_depthwise(const Act& x, const float* w, int k, float* y, double* stats, hipStream_t s, double* pool) {
   JH_REQUIRE(x.D == 1, "depthwise is 2D only");

@@ -94,6 +94,8 @@ struct ConvDesc {
   int nphase;
   ConvPhase phase[8];
   int cin, cout;
+  int latency_class;   // 1: the plan belongs to the single-frame-set class (time batch < 8): tile forms that trade
+                       // workgroups for fill (the whole-image tile) stay off.  A function of the class, never of the batch.
 };
 
 // Packed weights of one conv (all phases), see pack_conv_weights().

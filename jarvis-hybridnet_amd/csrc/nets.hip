@@ -141,6 +141,8 @@ int Plan::add_conv(const ParamMap& pm, const ConvDesc& d, const std::string& wke
   if (d.ostride > 1) taps = (d.nd == 2) ? 16 : 8;
   else taps = (size_t)d.k * d.k * (d.nd == 3 ? d.k : 1);
   const float *w = nullptr, *b = nullptr;
+  ConvDesc dd = d;
+  dd.latency_class = norm_block_kb == 0 ? 1 : 0;       // (the plan's time-batch class, set before build())
   if (get(pm, wkey, (size_t)d.cin * d.cout * taps, &w)) return 1;
   if (!bkey.empty() && get(pm, bkey, d.cout, &b)) return 1;
   // 3x3x3 stride-1 convs (the V2V residual blocks) run as Winograd F(2x2,3x3) x direct z
@@ -201,7 +203,7 @@ int Plan::add_conv(const ParamMap& pm, const ConvDesc& d, const std::string& wke
   snprintf(nm, sizeof nm, "conv%dd_k%ds%d%s_%dx%d@%d", d.nd, d.ostride > 1 ? (d.nd == 2 ? 4 : 2) : d.k,
            d.ostride > 1 ? 2 : d.stride, d.ostride > 1 ? (d4b ? "Tbf16x3" : "T") : (b3 || xb ? "bf16x3" : (wino ? "wino" : "")), d.cin, d.cout, y.W);
   push(nm, flops, bytes,
-       [this, d, cw, x, y, gate, want_stats, off, in_stats_off, in_inv, in_act, wino, wino_variant, b3, d4b, xb,
+       [this, d = dd, cw, x, y, gate, want_stats, off, in_stats_off, in_inv, in_act, wino, wino_variant, b3, d4b, xb,
         wino_tiles, sev = se ? *se : SeGate(), se_pool_off](hipStream_t s) {
     InNorm in;
     if (in_stats_off >= 0) { in.stats = sc((size_t)in_stats_off); in.inv = in_inv; in.act = in_act; }
