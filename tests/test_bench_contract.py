@@ -40,3 +40,23 @@ def test_bench_line():
     # path is the time_batch >= 8 class (row-streaming BiFPN nodes), i.e. the form the default bench runs
     assert line["parity_max_abs_mm_vs_reference_fixture"] < 1e-3
     assert line["config"]["time_batch"] >= 8
+    # every convolution row carries both floors, and `frac` is the binding (higher) one
+    convs = [k for k in line["kernels"] if k["kernel"].startswith(("conv2d_", "conv3d_"))]
+    assert convs and all(abs(k["frac"] - max(k["frac_mfma"], k["frac_hbm"])) < 1e-4 for k in convs)
+    assert all(k["bound"] == ("hbm" if k["frac_hbm"] > k["frac_mfma"] else "mfma") for k in convs)
+
+
+def test_bench_line_with_cpu_baseline_is_strict_on_any_host():
+    """With the CPU baseline leg on: the host-oracle comparison is made with the HIP gather indices substituted
+    (oracle.host_parity) and held to the north-star bar; every index flip of this host is a truncation tie."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1",
+                          "--time-batch", "8", "--streams", "1", "--cpu-seconds", "1", "--no-uint8", "--no-secondary",
+                          "--no-reduced-precision", "--profile-passes", "1"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["kind"] == "port"
+    assert line["parity_max_abs_mm_vs_host_oracle_same_indices"] < 1e-3
+    flips = line["host_oracle_index_flips"]
+    assert flips["of"] == 12 * 64 ** 3 and flips["flips"] <= 64
+    assert flips["max_dist_to_truncation_boundary"] <= 2.5e-4

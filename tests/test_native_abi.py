@@ -77,3 +77,24 @@ def test_module_state_dict_layout():
     # reference checkpoints load with strict=True
     sd = {k: v.clone() for k, v in hb.state_dict().items()}
     hb.load_state_dict(sd, strict=True)
+
+
+def test_roofline_pricing_takes_the_binding_floor():
+    """bench.price: a convolution is priced against the HIGHER of its MFMA and HBM floors (the few-channel 1x1 layers are
+    HBM-bound); everything else against HBM.  Pure arithmetic, no GPU."""
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT) if ROOT not in sys.path else None
+    bench = importlib.import_module("bench")
+    # conv2d_k1s1_16x8@128 at 384 images: 604 MB, 3.2 GFLOP algorithmic, 0.116 ms
+    px = 384 * 128 * 128
+    row = bench.price("conv2d_k1s1_16x8@128", 2.0 * px * 16 * 8, 4.0 * px * (16 + 8), 0.116e-3)
+    assert row["bound"] == "hbm" and 0.6 < row["frac"] < 0.7 and row["frac_mfma"] < 0.3
+    assert abs(row["frac"] - row["frac_hbm"]) < 1e-12
+    # the Winograd V2V convolution: MFMA-bound, executed FLOPs = 12 / 27 of the direct count with 46 -> 48 / 48 padding
+    vox = 32 * 32 ** 3
+    row = bench.price("conv3d_k3s1wino_46x46@32", 2.0 * vox * 46 * 46 * 27, 4.0 * vox * 92, 0.566e-3)
+    assert row["bound"] == "mfma" and 0.6 < row["frac"] < 0.7 and row["algorithmic_equiv"] > bench.PEAK_F32_MFMA_TFLOPS
+    # a kernel that is no convolution: HBM, whatever its FLOPs
+    row = bench.price("bifpn_node_56x56@64", 1e12, 880e6, 0.217e-3)
+    assert row["bound"] == "hbm" and "frac_mfma" not in row
