@@ -133,6 +133,9 @@ PREDICTOR_CASES = {
     # (projects/Example_Project/config.yaml:36-37: 12 cameras, ROI 144 / spacing 2 => 72^3): P3 = 80^2, hs = 162 ---
     "default_medium_320": dict(C=12, J=23, roi=144, spacing=2, bbox=320, center_size=320,
                                W=1280, H=1024, focal=1800.0, cseed=66, hseed=63, fseed=52, size="medium"),
+    # ... and fed as uint8 BGR bytes (the 32-channel stems' fused conversion at the 320-pixel geometry)
+    "default_medium_320_u8": dict(C=12, J=23, roi=144, spacing=2, bbox=320, center_size=320,
+                                  W=1280, H=1024, focal=1800.0, cseed=66, hseed=63, fseed=58, size="medium", u8=True),
     # --- sensor failures inside an otherwise valid 12-camera set (jarvis3D.py:143-157): camera 5 delivers an
     # all-zero (dropout) resp. all-one (saturated) frame.  A constant frame has zero variance everywhere except at
     # the zero padding of the stem, so its InstanceNorm statistics are the padding's; whether that camera passes the

@@ -49,7 +49,7 @@ EDGE_TAGS = ["cfg2_partial", "cfg2_one", "cfg3_partial", "cfg2_edge", "cfg2_edge
 
 # the reference's default configuration (medium / medium, 320 / 320 on the shipped 72^3 grid) and the sensor-failure
 # inputs (one camera all-zero / all-one inside a valid 12-camera set)
-DEFAULT_AND_DEAD = ["default_medium_320", "cfg3_cam_black", "cfg3_cam_white"]
+DEFAULT_AND_DEAD = ["default_medium_320", "default_medium_320_u8", "cfg3_cam_black", "cfg3_cam_white"]
 
 
 @pytest.mark.parametrize("tag", ["cfg2", "cfg3", "cfg2_none", "cfg2_u8", "cfg5", "ex72", "cfg3_medium", "cfg3_large"]

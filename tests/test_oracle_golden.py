@@ -122,7 +122,7 @@ def test_hybridnet(golden, tag):
 
 @pytest.mark.parametrize("tag", ["cfg2", "cfg2_none", "cfg2_u8", "cfg5", "ex72", "cfg3_medium", "cfg3_large",
                                  "cfg2_partial", "cfg2_one", "cfg3_partial", "cfg2_edge", "cfg2_edge_b", "cfg3_edge",
-                                 "default_medium_320", "cfg3_cam_black", "cfg3_cam_white"])
+                                 "default_medium_320", "default_medium_320_u8", "cfg3_cam_black", "cfg3_cam_white"])
 def test_predictor(golden, tag):
     c = cases.PREDICTOR_CASES[tag]
     inp = cases.predictor_inputs(tag)
