@@ -42,7 +42,9 @@ struct RowWgGeo {
   static constexpr int RSA = RC + 4;               // operand-block row stride (floats): 16 rows on distinct banks
   static constexpr int ROWB = kWPX18 * RC * 4;     // bytes per ring row
   static constexpr int OPB = 16 * RSA * 4;         // bytes per operand block
-  static constexpr size_t lds_bytes() { return (size_t)3 * ROWB + 2 * OPB; }
+  // helper waves (HELP forms): the 2 pixels x 4 quads x NW channel groups of ring pixels 16, 17 -- see the kernel
+  static constexpr int NH = (NW * 8 + 63) / 64;
+  static constexpr size_t lds_bytes(bool help) { return (size_t)(help ? 4 : 3) * ROWB + 2 * OPB; }
   static_assert(RC % 8 == 0 && NW <= 16, "channel count of the workgroup row-streaming node");
 };
 typedef float wf2 __attribute__((ext_vector_type(2)));
@@ -51,20 +53,35 @@ typedef unsigned wu4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 }  // namespace
 
-template <int RC, int NIN, int M1, int M2, int ACT, bool POOL>
-__global__ __launch_bounds__(RowWgGeo<RC>::NW * 64)
+// HELP (round 6): a ring row is 18 pixels x 4 quads = 72 items per channel group, so the second fusion round of a wave
+// carried 8 items on 64 lanes -- loads, FMAs and the two transcendentals of SiLU issued for an eighth of a wave, on
+// every one of the 3 / 3 / 2 / 2 waves of a SIMD.  With HELP the channel-group waves fuse pixels 0..15 only and NH extra
+// waves (one per 8 channel groups; they land on the SIMDs that hold two group waves) fuse pixels 16, 17 of ALL groups,
+// one row AHEAD of the group waves (so the row's one barrier orders their writes before the depthwise that reads
+// them), which takes a fourth ring slot: the slot of row r + 1 is still being read as row r - 2 otherwise.  The
+// arithmetic of every item is unchanged: both forms give the same bits.
+template <int RC, int NIN, int M1, int M2, int ACT, bool POOL, bool HELP>
+__global__ __launch_bounds__((RowWgGeo<RC>::NW + (HELP ? RowWgGeo<RC>::NH : 0)) * 64)
 void bifpn_rows_wg_kernel(const NodeArgs a, int seg_rows, int strips) {
   using GEO = RowWgGeo<RC>;
-  constexpr int K8 = GEO::K8, RSA = GEO::RSA, kRowB = GEO::ROWB, kOpOff = 3 * GEO::ROWB, kOpB = GEO::OPB;
+  constexpr int NSLOT = HELP ? 4 : 3;
+  constexpr int K8 = GEO::K8, RSA = GEO::RSA, kRowB = GEO::ROWB, kOpOff = NSLOT * GEO::ROWB, kOpB = GEO::OPB;
   constexpr int kModes[3] = {FUSE_SAME, M1, M2};
-  constexpr int NIT = 2;                           // fused items per lane: pixels sub and 16 + sub (sub < 2)
+  constexpr int NIT = HELP ? 1 : 2;                // fused items per lane: pixels sub and 16 + sub (sub < 2)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int q = lane & 3, sub = lane >> 2;         // channel quad inside the wave's 16 channels, pixel slot 0..15
-  const int c = wave * 16 + q * 4;
+  // (the two roles are two instantiations of the body: `helper` must be a compile-time constant or the channel masks
+  //  of the 160-channel form stop folding and the group waves' row loop fills with exec-masked regions and spills)
+  auto body = [&](auto helper_c) __attribute__((always_inline)) {
+  constexpr bool helper = decltype(helper_c)::value;
+  const int hitem = (wave - GEO::NW) * 64 + lane;  // helper lanes: (channel group, pixel 16 / 17, quad)
+  const int q = lane & 3;                          // channel quad inside the 16 channels of a group
+  const int sub = helper ? 16 + ((hitem >> 2) & 1) : lane >> 2;    // ring pixel of the lane's (first) item
+  const int grp = helper ? hitem >> 3 : wave;
+  const int c = grp * 16 + q * 4;
   // (88 channels = 5.5 groups: the last wave's quads 2, 3 and its output channels 88..95 do not exist)
-  const bool cq_ok = RC % 16 == 0 || c < RC;
+  const bool cq_ok = (RC % 16 == 0 || c < RC) && (!helper || hitem < GEO::NW * 8);
   const int cs = cq_ok ? c : 0;                    // a valid quad for the loads of per-channel constants
   const int sx = blockIdx.x % strips, seg = blockIdx.x / strips, n = blockIdx.y;
   const int ox0 = sx * 16, y_begin = seg * seg_rows, y_end = min(a.H, y_begin + seg_rows);
@@ -94,20 +111,6 @@ void bifpn_rows_wg_kernel(const NodeArgs a, int seg_rows, int strips) {
       bb[j] += -m4[j] * ak1;
     }
   }
-  wf4 dwr[9];                                      // depthwise weights of this lane's channel quad
-#pragma unroll
-  for (int t = 0; t < 9; ++t) dwr[t] = *reinterpret_cast<const wf4*>(a.dw + t * RC + cs);
-  // pointwise weights of output column block `wave` for all RC / 8 channel steps (packed as for bifpn_rows.hip:
-  // weights are the A operand, pixels the B operand, so a lane's accumulator is four consecutive channels
-  // 16 wave + 4 (lane >> 4) .. + 3 of pixel lane & 15)
-  constexpr int NCB = GEO::NW;
-  wf2 bw[K8];
-#pragma unroll
-  for (int k8 = 0; k8 < K8; ++k8)
-    bw[k8] = *reinterpret_cast<const wf2*>(a.pw + ((size_t)(k8 * NCB + wave) * 64 + lane) * 2);
-  wf4 b4 = (wf4){0.f, 0.f, 0.f, 0.f};
-  if (a.bias) b4 = *reinterpret_cast<const wf4*>(a.bias + wave * 16 + kq * 4);
-
   __amdgpu_buffer_rsrc_t rs[NIN];
   int rowstep[NIN];                                // bytes per source row of input k
 #pragma unroll
@@ -161,7 +164,7 @@ void bifpn_rows_wg_kernel(const NodeArgs a, int seg_rows, int strips) {
   wf4 raw[NIN][NIT];
   // (see bifpn_rows.hip: an up-sampled input changes its source row only every 2nd output row; `all_c` is a
   //  compile-time flag because loads under a run-time branch make the compiler's in-order wait counts pessimistic)
-  auto issue = [&](int yf, auto all_c) __attribute__((always_inline)) {       // (yf inside the image)
+  auto issue = [&](int yf, auto all_c, wf4 (&raw)[NIN][NIT]) __attribute__((always_inline)) {   // (yf inside the image)
     constexpr bool all = decltype(all_c)::value;
     int srow[NIN];
 #pragma unroll
@@ -178,7 +181,7 @@ void bifpn_rows_wg_kernel(const NodeArgs a, int seg_rows, int strips) {
               __builtin_bit_cast(wf4, __builtin_amdgcn_raw_buffer_load_b128(rs[k], voff[k][it], srow[k], 0));
   };
   // fused + activated row yf -> ring slot (yf + 1) % 3 (zeros outside the image: the depthwise padding)
-  auto fuse = [&](int yf, int slot) __attribute__((always_inline)) {
+  auto fuse = [&](int yf, int slot, const wf4 (&raw)[NIN][NIT]) __attribute__((always_inline)) {
     unsigned char* dst = smem + slot * kRowB + fdst;
     if ((unsigned)yf >= (unsigned)a.H) {                             // (uniform) padding row
 #pragma unroll
@@ -204,16 +207,52 @@ void bifpn_rows_wg_kernel(const NodeArgs a, int seg_rows, int strips) {
     }
   };
 
+  if constexpr (helper) {
+    // rows y_begin - 1 .. y_begin + 1 before the group waves' first depthwise (the barrier in front of their row loop),
+    // then row yf + 1 in front of the barrier of step yf.  Row r lives in slot (r + 1) & 3.
+    wf4 hr[3][NIN][NIT];
+    __builtin_amdgcn_s_waitcnt(0);
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      if ((unsigned)(y_begin - 1 + j) < (unsigned)a.H) issue(y_begin - 1 + j, std::true_type{}, hr[j]);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) fuse(y_begin - 1 + j, (y_begin + j) & 3, hr[j]);
+    if (y_begin + 2 <= y_end && y_begin + 2 < a.H) issue(y_begin + 2, std::true_type{}, hr[0]);
+    lds_barrier();
+    for (int yf = y_begin + 1; yf <= y_end; ++yf) {
+      if (yf + 1 <= y_end) {
+        fuse(yf + 1, (yf + 2) & 3, hr[0]);
+        if (yf + 2 <= y_end && yf + 2 < a.H) issue(yf + 2, std::true_type{}, hr[0]);
+      }
+      lds_barrier();
+    }
+    return;
+  }
+  wf4 dwr[9];                                      // depthwise weights of this lane's channel quad
+#pragma unroll
+  for (int t = 0; t < 9; ++t) dwr[t] = *reinterpret_cast<const wf4*>(a.dw + t * RC + cs);
+  // pointwise weights of output column block `wave` for all RC / 8 channel steps (packed as for bifpn_rows.hip:
+  // weights are the A operand, pixels the B operand, so a lane's accumulator is four consecutive channels
+  // 16 wave + 4 (lane >> 4) .. + 3 of pixel lane & 15)
+  constexpr int NCB = GEO::NW;
+  wf2 bw[K8];
+#pragma unroll
+  for (int k8 = 0; k8 < K8; ++k8)
+    bw[k8] = *reinterpret_cast<const wf2*>(a.pw + ((size_t)(k8 * NCB + wave) * 64 + lane) * 2);
+  wf4 b4 = (wf4){0.f, 0.f, 0.f, 0.f};
+  if (a.bias) b4 = *reinterpret_cast<const wf4*>(a.bias + wave * 16 + kq * 4);
+
   wf4 s1 = (wf4){0.f, 0.f, 0.f, 0.f}, s2 = s1;
   __builtin_amdgcn_s_waitcnt(0);                   // (the preamble's loads: see bifpn_rows.hip)
-  int slot = (y_begin + 3) % 3;                    // slot of row yf = y_begin - 1: (yf + 1) % 3
+  int slot = y_begin % NSLOT;                      // slot of row yf = y_begin - 1: (yf + 1) % NSLOT
 
   auto row = [&](int yf, auto next_all_c, auto out_c) __attribute__((always_inline)) {
-    fuse(yf, slot);
-    if (yf + 1 <= y_end && yf + 1 < a.H) issue(yf + 1, next_all_c);
+    fuse(yf, slot, raw);
+    if (yf + 1 <= y_end && yf + 1 < a.H) issue(yf + 1, next_all_c, raw);
     const int y = yf - 1;                               // output row whose three ring rows are now complete
-    const int s_top = slot == 0 ? 1 : (slot == 1 ? 2 : 0);          // slot of row y - 1 = (slot + 1) % 3
-    slot = s_top;
+    // slot of row y - 1 = yf - 2, then the slot of the next row
+    const int s_top = HELP ? (slot + 2) & 3 : (slot == 0 ? 1 : (slot == 1 ? 2 : 0));
+    slot = HELP ? (slot + 1) & 3 : s_top;
     if (!decltype(out_c)::value) return;             // (the two rows above the segment's first output row)
     // the operand buffer of this row: by row parity (next_all_c is true in the half of the unrolled loop that
     // produces the EVEN output rows)
@@ -225,7 +264,7 @@ void bifpn_rows_wg_kernel(const NodeArgs a, int seg_rows, int strips) {
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy) {
         const unsigned char* src = smem + rs_ * kRowB + dsrc;
-        rs_ = rs_ == 2 ? 0 : rs_ + 1;
+        rs_ = HELP ? (rs_ + 1) & 3 : (rs_ == 2 ? 0 : rs_ + 1);
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx)
           d = __builtin_elementwise_fma(*reinterpret_cast<const wf4*>(src + dx * RC * 4), dwr[dy * 3 + dx], d);
@@ -265,9 +304,10 @@ void bifpn_rows_wg_kernel(const NodeArgs a, int seg_rows, int strips) {
   };
   // (segments start on even rows -- the launcher -- so row y_begin - 1 is odd and the rows requested from the first
   //  half of the unrolled body are even: all inputs; from the second half odd: same-level inputs only)
-  if (y_begin - 1 >= 0) issue(y_begin - 1, std::true_type{});
+  if (y_begin - 1 >= 0) issue(y_begin - 1, std::true_type{}, raw);
   row(y_begin - 1, std::true_type{}, std::false_type{});
   row(y_begin, std::false_type{}, std::false_type{});
+  if (HELP) lds_barrier();                           // pixels 16, 17 of the first three rows are in the ring
   for (int yf = y_begin + 1; yf <= y_end; yf += 2) {
     row(yf, std::true_type{}, std::true_type{});
     if (yf + 1 <= y_end) row(yf + 1, std::false_type{}, std::true_type{});
@@ -288,6 +328,9 @@ void bifpn_rows_wg_kernel(const NodeArgs a, int seg_rows, int strips) {
       if (mrow == 0 && co_ok) stat_add(a.stats + ((size_t)n * a.cout_p + ch) * kStatW, t1, t2);
     }
   }
+  };
+  if (HELP && wave >= GEO::NW) body(std::true_type{});
+  else body(std::false_type{});
 }
 
 // Shapes of the workgroup form (the channel count is checked by the caller, bifpn_rows_eligible): as many output
@@ -296,7 +339,7 @@ bool bifpn_rows_wg_shape_ok(const NodeArgs& a) {
   return (a.Cp == 160 || a.Cp == 88) && a.cout_p == a.Cp && a.cout_p16 == (a.Cp + 15) / 16 * 16;
 }
 
-template <int RC>
+template <int RC, bool HELP>
 static int launch_rows_wg_rc(const NodeArgs& a, hipStream_t s) {
   const int strips = (a.W + 15) / 16;
   // Rows per workgroup: a function of the node and of the predictor's time-batch CLASS only (the float partial sums
@@ -318,10 +361,19 @@ static int launch_rows_wg_rc(const NodeArgs& a, hipStream_t s) {
   seg_rows = (seg_rows + 1) & ~1;
   if (seg_rows > a.H) seg_rows = a.H;
   const int segs = (a.H + seg_rows - 1) / seg_rows;
-  const size_t lds = RowWgGeo<RC>::lds_bytes();
-  const dim3 grid(strips * segs, a.N), block(RowWgGeo<RC>::NW * 64);
-#define JH_ROWS(NIN, M1, M2, ACT, POOL) \
-  hipLaunchKernelGGL((bifpn_rows_wg_kernel<RC, NIN, M1, M2, ACT, POOL>), grid, block, lds, s, a, seg_rows, strips)
+  const size_t lds = RowWgGeo<RC>::lds_bytes(HELP);
+  const dim3 grid(strips * segs, a.N), block((RowWgGeo<RC>::NW + (HELP ? RowWgGeo<RC>::NH : 0)) * 64);
+#define JH_ROWS(NIN, M1, M2, ACT, POOL)                                                                            \
+  do {                                                                                                             \
+    auto kern = bifpn_rows_wg_kernel<RC, NIN, M1, M2, ACT, POOL, HELP>;                                            \
+    static bool big = false;                                                                                       \
+    if (!big && lds > 64 * 1024) {                                                                                 \
+      JH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                        \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                   \
+      big = true;                                                                                                  \
+    }                                                                                                              \
+    hipLaunchKernelGGL(kern, grid, block, lds, s, a, seg_rows, strips);                                            \
+  } while (0)
   JH_REQUIRE(!a.y_pool || (a.act == ACT_SILU && a.H % 2 == 0 && (a.n_in == 2 || a.mode[1] == FUSE_SAME)),
              "workgroup row-streaming node: pooled output");
   if (a.n_in == 2 && a.mode[1] == FUSE_SAME) {       // (bottom-up node of the coarsest level: P7 from P7_in and pooled P6)
@@ -347,8 +399,10 @@ static int launch_rows_wg_rc(const NodeArgs& a, hipStream_t s) {
 }
 
 int launch_bifpn_rows_wg(const NodeArgs& a, hipStream_t s) {
-  if (a.Cp == 88) return launch_rows_wg_rc<88>(a, s);
-  return launch_rows_wg_rc<160>(a, s);
+  // (both forms give the same bits; JH_NODE_WG_HELP=0: every channel-group wave fuses its own pixels 16, 17)
+  const bool help = JH_ENV_KNOB("JH_NODE_WG_HELP") != 0;
+  if (a.Cp == 88) return help ? launch_rows_wg_rc<88, true>(a, s) : launch_rows_wg_rc<88, false>(a, s);
+  return help ? launch_rows_wg_rc<160, true>(a, s) : launch_rows_wg_rc<160, false>(a, s);
 }
 
 }  // namespace jh
