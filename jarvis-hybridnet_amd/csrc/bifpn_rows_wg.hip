@@ -7,15 +7,16 @@
 // next to anything else, the LDS -- the tile kernel re-streams them per tile and runs at 8-15 % of HBM there
 // (3.6 ms per P3 node of the large model at 384 images).  Here
 //   * wave w owns the 16 channels [16 w, 16 w + 16) on BOTH sides of the depthwise: it fuses them into its own
-//     channel slice of the three-row ring in LDS (no synchronisation: the depthwise reads per channel), and it owns
+//     channel slice of the row ring in LDS (no synchronisation: the depthwise reads per channel), and it owns
 //     output column block w of the pointwise: its 16 x RC weight slice stays in RC / 4 = 40 registers for the strip,
 //   * the 16 x RC operand block (depthwise output of one row) is the only thing the waves share: double-buffered by
 //     row parity, ONE workgroup barrier per row (LDS traffic only: the next row's global loads stay in flight),
-//   * per row and wave: 2 fused items per lane (18 pixels x 4 quads over 64 lanes), one depthwise pixel per lane
+//   * per row and wave: one fused item per lane (16 pixels x 4 quads; pixels 16, 17 of the 18: the helper waves,
+//     see the kernel), one depthwise pixel per lane
 //     (9 ring reads, 9 packed FMAs), RC / 8 operand reads + RC / 4 MFMAs (two accumulators: even / odd channel
 //     pairs), bias + statistics + one 16-byte store; the 2 x 2 max-pooled output is carried in registers between the
 //     two halves of the unrolled row loop, so every variant can write it.
-// One workgroup (10 waves at 160 channels, <= 168 registers) per CU; 55.5 KB of LDS.
+// One workgroup (10 + 2 waves at 160 channels, <= 168 registers) per CU; 67 KB of LDS (four ring rows).
 //
 // Also (round 4, single-frame latency of the medium / large models):
 //   * 88 channels = 5.5 channel groups: six waves, the last one's quads 2, 3 and output channels 88..95 masked.  At
@@ -42,9 +43,9 @@ struct RowWgGeo {
   static constexpr int RSA = RC + 4;               // operand-block row stride (floats): 16 rows on distinct banks
   static constexpr int ROWB = kWPX18 * RC * 4;     // bytes per ring row
   static constexpr int OPB = 16 * RSA * 4;         // bytes per operand block
-  // helper waves (HELP forms): the 2 pixels x 4 quads x NW channel groups of ring pixels 16, 17 -- see the kernel
-  static constexpr int NH = (NW * 8 + 63) / 64;
-  static constexpr size_t lds_bytes(bool help) { return (size_t)(help ? 4 : 3) * ROWB + 2 * OPB; }
+  static constexpr int NH = 2;                     // helper waves (see the kernel)
+  static constexpr int NSLOT = 4;                  // ring rows
+  static constexpr size_t lds_bytes() { return (size_t)NSLOT * ROWB + 2 * OPB; }
   static_assert(RC % 8 == 0 && NW <= 16, "channel count of the workgroup row-streaming node");
 };
 typedef float wf2 __attribute__((ext_vector_type(2)));
@@ -53,62 +54,86 @@ typedef unsigned wu4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 }  // namespace
 
-// HELP (round 6): a ring row is 18 pixels x 4 quads = 72 items per channel group, so the second fusion round of a wave
-// carried 8 items on 64 lanes -- loads, FMAs and the two transcendentals of SiLU issued for an eighth of a wave, on
-// every one of the 3 / 3 / 2 / 2 waves of a SIMD.  With HELP the channel-group waves fuse pixels 0..15 only and NH extra
-// waves (one per 8 channel groups; they land on the SIMDs that hold two group waves) fuse pixels 16, 17 of ALL groups,
-// one row AHEAD of the group waves (so the row's one barrier orders their writes before the depthwise that reads
-// them), which takes a fourth ring slot: the slot of row r + 1 is still being read as row r - 2 otherwise.  The
-// arithmetic of every item is unchanged: both forms give the same bits.
-template <int RC, int NIN, int M1, int M2, int ACT, bool POOL, bool HELP>
-__global__ __launch_bounds__((RowWgGeo<RC>::NW + (HELP ? RowWgGeo<RC>::NH : 0)) * 64)
+// Helper waves (round 6).  A ring row is 18 pixels x 4 quads = 72 fusion items per channel group: the second fusion
+// round of a group wave carried 8 items on 64 lanes -- loads, FMAs and the two transcendentals of SiLU issued for an
+// eighth of a wave -- and the NW group waves sit unevenly on the four SIMDs (160 channels: 3 / 3 / 2 / 2; 88: 2 / 2 / 1 / 1).
+// So the workgroup has NH = 2 more waves (they land on the SIMDs with the fewest group waves: waves w and w + 4 share a SIMD, tools/wave_simd_probe.hip):
+//   * item 0 of a helper lane: pixels 16, 17 of ALL channel groups (8 NW items over the two helpers),
+//   * items 1 .. DPH (experiment, off: launch_bifpn_rows_wg): the whole 16-pixel fusion round of DPH group waves of the
+//     crowded SIMDs (helper h serves groups h, h + 4, ..), which then do no fusion and issue no global loads (ROLE 1),
+// one row AHEAD of the group waves, so that the row's one barrier orders the helpers' ring writes before the depthwise
+// that reads them; that takes a fourth ring slot (the slot of row r + 1 is still being read as row r - 2 otherwise).
+// The arithmetic of every item is unchanged: every form gives the same bits.
+template <int RC, int NIN, int M1, int M2, int ACT, bool POOL, int DPH>
+__global__ __launch_bounds__((RowWgGeo<RC>::NW + RowWgGeo<RC>::NH) * 64)
 void bifpn_rows_wg_kernel(const NodeArgs a, int seg_rows, int strips) {
   using GEO = RowWgGeo<RC>;
-  constexpr int NSLOT = HELP ? 4 : 3;
+  constexpr int NSLOT = GEO::NSLOT, NW = GEO::NW, NH = GEO::NH;
   constexpr int K8 = GEO::K8, RSA = GEO::RSA, kRowB = GEO::ROWB, kOpOff = NSLOT * GEO::ROWB, kOpB = GEO::OPB;
   constexpr int kModes[3] = {FUSE_SAME, M1, M2};
-  constexpr int NIT = HELP ? 1 : 2;                // fused items per lane: pixels sub and 16 + sub (sub < 2)
+  static_assert(NSLOT == 4 && 4 * (DPH - 1) + NH - 1 < NW, "delegated channel groups");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  // (the two roles are two instantiations of the body: `helper` must be a compile-time constant or the channel masks
-  //  of the 160-channel form stop folding and the group waves' row loop fills with exec-masked regions and spills)
-  auto body = [&](auto helper_c) __attribute__((always_inline)) {
-  constexpr bool helper = decltype(helper_c)::value;
-  const int hitem = (wave - GEO::NW) * 64 + lane;  // helper lanes: (channel group, pixel 16 / 17, quad)
-  const int q = lane & 3;                          // channel quad inside the 16 channels of a group
-  const int sub = helper ? 16 + ((hitem >> 2) & 1) : lane >> 2;    // ring pixel of the lane's (first) item
-  const int grp = helper ? hitem >> 3 : wave;
-  const int c = grp * 16 + q * 4;
-  // (88 channels = 5.5 groups: the last wave's quads 2, 3 and its output channels 88..95 do not exist)
-  const bool cq_ok = (RC % 16 == 0 || c < RC) && (!helper || hitem < GEO::NW * 8);
-  const int cs = cq_ok ? c : 0;                    // a valid quad for the loads of per-channel constants
   const int sx = blockIdx.x % strips, seg = blockIdx.x / strips, n = blockIdx.y;
   const int ox0 = sx * 16, y_begin = seg * seg_rows, y_end = min(a.H, y_begin + seg_rows);
+  // (the roles are instantiations of one body: the role must be a compile-time constant or the channel masks of the
+  //  160-channel form stop folding and the group waves' row loop fills with exec-masked regions and spills)
+  // ROLE 0: group wave that fuses its own pixels 0..15; 1: group wave whose ring rows a helper writes; 2: helper
+  auto body = [&](auto role_c) __attribute__((always_inline)) {
+  constexpr int ROLE = decltype(role_c)::value;
+  constexpr int NI = ROLE == 0 ? 1 : (ROLE == 1 ? 0 : 1 + DPH);      // fusion items per lane and row
+  constexpr int NIA = NI > 0 ? NI : 1;
   const int mrow = lane & 15, kq = lane >> 4;
 
-  // ---- per-lane constants --------------------------------------------------------------------------------
-  // folded norm + fusion weights of this lane's channel quad: fused = sum_k x_k a_k + B
-  wf4 ak[NIN], bb = (wf4){0.f, 0.f, 0.f, 0.f};
+  // ---- fusion items of this lane: ring pixel, channel quad ---------------------------------------------------
+  // (88 channels = 5.5 groups: quads 2, 3 of the last group and its output channels 88..95 do not exist)
+  int ipx[NIA], ic[NIA];
+  bool iok[NIA];
 #pragma unroll
-  for (int k = 0; k < NIN; ++k) {
-    float m4[4] = {0.f, 0.f, 0.f, 0.f}, r4[4] = {1.f, 1.f, 1.f, 1.f};
-    if (a.st[k]) {
+  for (int i = 0; i < NI; ++i) {
+    if (ROLE == 0) {
+      ipx[i] = lane >> 2;
+      ic[i] = wave * 16 + (lane & 3) * 4;
+      iok[i] = RC % 16 == 0 || ic[i] < RC;
+    } else if (i == 0) {
+      constexpr int per = NW * 8 / NH;
+      const int hitem = (wave - NW) * per + lane;                     // (channel group, pixel 16 / 17, quad)
+      ipx[i] = 16 + ((hitem >> 2) & 1);
+      ic[i] = (hitem >> 3) * 16 + (hitem & 3) * 4;
+      iok[i] = lane < per && ic[i] < RC;
+    } else {
+      ipx[i] = lane >> 2;
+      ic[i] = ((wave - NW) + 4 * (i - 1)) * 16 + (lane & 3) * 4;
+      iok[i] = RC % 16 == 0 || ic[i] < RC;
+    }
+  }
+  // folded norm + fusion weights of an item's channel quad: fused = sum_k x_k a_k + B
+  wf4 ak[NIA][NIN], bb[NIA];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int cs = iok[i] ? ic[i] : 0;               // a valid quad for the loads of per-channel constants
+    bb[i] = (wf4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < NIN; ++k) {
+      float m4[4] = {0.f, 0.f, 0.f, 0.f}, r4[4] = {1.f, 1.f, 1.f, 1.f};
+      if (a.st[k]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const double* st = a.st[k] + ((size_t)n * RC + cs + j) * kStatW;
+          const double mu = exact_read(st) * (double)a.inv_cnt[k];
+          double var = exact_read(st + kLimbs) * (double)a.inv_cnt[k] - mu * mu;
+          if (var < 0.0) var = 0.0;
+          m4[j] = (float)mu;
+          r4[j] = (float)(1.0 / sqrt(var + 1e-5));
+        }
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const double* st = a.st[k] + ((size_t)n * RC + cs + j) * kStatW;
-        const double mu = exact_read(st) * (double)a.inv_cnt[k];
-        double var = exact_read(st + kLimbs) * (double)a.inv_cnt[k] - mu * mu;
-        if (var < 0.0) var = 0.0;
-        m4[j] = (float)mu;
-        r4[j] = (float)(1.0 / sqrt(var + 1e-5));
+        const float ak1 = a.w[k] * r4[j];
+        ak[i][k][j] = ak1;
+        bb[i][j] += -m4[j] * ak1;
       }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float ak1 = a.w[k] * r4[j];
-      ak[k][j] = ak1;
-      bb[j] += -m4[j] * ak1;
     }
   }
   __amdgpu_buffer_rsrc_t rs[NIN];
@@ -121,24 +146,94 @@ void bifpn_rows_wg_kernel(const NodeArgs a, int seg_rows, int strips) {
                                               0x00020000);
     rowstep[k] = (a.W >> sh) * RC * 4;
   }
-  // the two items of this lane in a fused row (pixels sub and 16 + sub of the 18): load offsets inside a source row
-  // (bit 31 = outside the image or no item: the buffer load returns 0) and the 0 / 1 mask of the zero padding
-  int voff[NIN][NIT];
-  float msk[NIT];
-  bool has[NIT];
+  // load offsets of the items inside a source row (bit 31 = outside the image or no item: the buffer load returns 0),
+  // the 0 / 1 mask of the zero padding, the ring address
+  int voff[NIA][NIN], fdst[NIA];
+  float msk[NIA];
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int px = it * 16 + sub, ix = ox0 - 1 + px;
-    has[it] = px < kWPX18 && cq_ok;
-    const bool ok = has[it] && (unsigned)ix < (unsigned)a.W;
-    msk[it] = ok ? 1.f : 0.f;
+  for (int i = 0; i < NI; ++i) {
+    const int ix = ox0 - 1 + ipx[i];
+    const bool ok = iok[i] && (unsigned)ix < (unsigned)a.W;
+    msk[i] = ok ? 1.f : 0.f;
 #pragma unroll
     for (int k = 0; k < NIN; ++k) {
       const int sh = kModes[k] == FUSE_UP2 ? 1 : (kModes[k] == FUSE_UP4 ? 2 : 0);
-      voff[k][it] = ok ? ((ix >> sh) * RC + c) * 4 : (int)0x80000000;
+      voff[i][k] = ok ? ((ix >> sh) * RC + ic[i]) * 4 : (int)0x80000000;
     }
+    fdst[i] = (ipx[i] * RC + ic[i]) * 4;                        // + ring slot
   }
-  const int fdst = (sub * RC + c) * 4;                          // + 16 pixels (imm) + ring slot
+  // (see bifpn_rows.hip: an up-sampled input changes its source row only every 2nd output row; `all_c` is a
+  //  compile-time flag because loads under a run-time branch make the compiler's in-order wait counts pessimistic)
+  auto issue = [&](int yf, auto all_c, wf4 (&raw)[NIA][NIN]) __attribute__((always_inline)) {   // (yf inside the image)
+    constexpr bool all = decltype(all_c)::value;
+    int srow[NIN];
+#pragma unroll
+    for (int k = 0; k < NIN; ++k) {
+      const int sh = kModes[k] == FUSE_UP2 ? 1 : (kModes[k] == FUSE_UP4 ? 2 : 0);
+      srow[k] = (yf >> sh) * rowstep[k];
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int k = 0; k < NIN; ++k)
+        if (all || kModes[k] == FUSE_SAME)
+          raw[i][k] =
+              __builtin_bit_cast(wf4, __builtin_amdgcn_raw_buffer_load_b128(rs[k], voff[i][k], srow[k], 0));
+  };
+  // fused + activated row yf -> its ring slot (zeros outside the image: the depthwise padding)
+  auto fuse = [&](int yf, int slot, const wf4 (&raw)[NIA][NIN]) __attribute__((always_inline)) {
+    unsigned char* dst = smem + slot * kRowB;
+    if ((unsigned)yf >= (unsigned)a.H) {                             // (uniform) padding row
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+        if (iok[i]) *reinterpret_cast<wf4*>(dst + fdst[i]) = (wf4){0.f, 0.f, 0.f, 0.f};
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      wf4 v = bb[i];
+#pragma unroll
+      for (int k = 0; k < NIN; ++k) v = __builtin_elementwise_fma(raw[i][k], ak[i][k], v);
+      if (ACT == ACT_SILU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] * __builtin_amdgcn_rcpf(1.f + __expf(-v[j]));
+      } else if (ACT == ACT_RELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+      // (pixels 0 and 17 of a strip at the image border: the depthwise padding)
+      v *= (wf4){msk[i], msk[i], msk[i], msk[i]};
+      if (iok[i]) *reinterpret_cast<wf4*>(dst + fdst[i]) = v;
+    }
+  };
+
+  if constexpr (ROLE == 2) {
+    // rows y_begin - 1 .. y_begin + 1 before the group waves' first depthwise (the barrier in front of their row loop),
+    // then row yf + 1 in front of the barrier of step yf.  Row r lives in slot (r + 1) & 3.
+    wf4 ra[NIA][NIN], rb[NIA][NIN];
+    __builtin_amdgcn_s_waitcnt(0);
+    if (y_begin - 1 >= 0) issue(y_begin - 1, std::true_type{}, ra);
+    issue(y_begin, std::true_type{}, rb);
+    fuse(y_begin - 1, y_begin & 3, ra);
+    if (y_begin + 1 < a.H) issue(y_begin + 1, std::true_type{}, ra);
+    fuse(y_begin, (y_begin + 1) & 3, rb);
+    fuse(y_begin + 1, (y_begin + 2) & 3, ra);
+    if (y_begin + 2 <= y_end && y_begin + 2 < a.H) issue(y_begin + 2, std::true_type{}, ra);
+    lds_barrier();
+    for (int yf = y_begin + 1; yf <= y_end; ++yf) {
+      if (yf + 1 <= y_end) {
+        fuse(yf + 1, (yf + 2) & 3, ra);
+        if (yf + 2 <= y_end && yf + 2 < a.H) issue(yf + 2, std::true_type{}, ra);
+      }
+      lds_barrier();
+    }
+    return;
+  }
+
+  // ---- group waves: depthwise + pointwise of channel group `wave` --------------------------------------------
+  const int sub = lane >> 2, c = wave * 16 + (lane & 3) * 4;    // pixel slot, channel quad of the depthwise
+  const bool cq_ok = RC % 16 == 0 || c < RC;
+  const int cs = cq_ok ? c : 0;
   const int dsrc = (sub * RC + c) * 4;                          // + ring slot + tap pixel (imm)
   const int adst = kOpOff + (sub * RSA + c) * 4;                // + operand buffer
   const int ard = kOpOff + (mrow * RSA) * 4 + kq * 8;           // + operand buffer + channel step (imm)
@@ -161,98 +256,32 @@ void bifpn_rows_wg_kernel(const NodeArgs a, int seg_rows, int strips) {
     if (!(mrow & 1) && co_ok && pok) pbase = (((ox0 + mrow) >> 1) * a.cout_p + wave * 16 + kq * 4) * 4;
   }
   wf4 park = (wf4){0.f, 0.f, 0.f, 0.f};
-  wf4 raw[NIN][NIT];
-  // (see bifpn_rows.hip: an up-sampled input changes its source row only every 2nd output row; `all_c` is a
-  //  compile-time flag because loads under a run-time branch make the compiler's in-order wait counts pessimistic)
-  auto issue = [&](int yf, auto all_c, wf4 (&raw)[NIN][NIT]) __attribute__((always_inline)) {   // (yf inside the image)
-    constexpr bool all = decltype(all_c)::value;
-    int srow[NIN];
-#pragma unroll
-    for (int k = 0; k < NIN; ++k) {
-      const int sh = kModes[k] == FUSE_UP2 ? 1 : (kModes[k] == FUSE_UP4 ? 2 : 0);
-      srow[k] = (yf >> sh) * rowstep[k];
-    }
-#pragma unroll
-    for (int it = 0; it < NIT; ++it)
-#pragma unroll
-      for (int k = 0; k < NIN; ++k)
-        if (all || kModes[k] == FUSE_SAME)
-          raw[k][it] =
-              __builtin_bit_cast(wf4, __builtin_amdgcn_raw_buffer_load_b128(rs[k], voff[k][it], srow[k], 0));
-  };
-  // fused + activated row yf -> ring slot (yf + 1) % 3 (zeros outside the image: the depthwise padding)
-  auto fuse = [&](int yf, int slot, const wf4 (&raw)[NIN][NIT]) __attribute__((always_inline)) {
-    unsigned char* dst = smem + slot * kRowB + fdst;
-    if ((unsigned)yf >= (unsigned)a.H) {                             // (uniform) padding row
-#pragma unroll
-      for (int it = 0; it < NIT; ++it)
-        if (has[it]) *reinterpret_cast<wf4*>(dst + it * 16 * RC * 4) = (wf4){0.f, 0.f, 0.f, 0.f};
-      return;
-    }
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      wf4 v = bb;
-#pragma unroll
-      for (int k = 0; k < NIN; ++k) v = __builtin_elementwise_fma(raw[k][it], ak[k], v);
-      if (ACT == ACT_SILU) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = v[j] * __builtin_amdgcn_rcpf(1.f + __expf(-v[j]));
-      } else if (ACT == ACT_RELU) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-      }
-      // (pixel 0 of the strip is item 0 of the lanes sub == 0, pixel 17 item 1 of sub == 1: both items are masked)
-      v *= (wf4){msk[it], msk[it], msk[it], msk[it]};
-      if (has[it]) *reinterpret_cast<wf4*>(dst + it * 16 * RC * 4) = v;
-    }
-  };
-
-  if constexpr (helper) {
-    // rows y_begin - 1 .. y_begin + 1 before the group waves' first depthwise (the barrier in front of their row loop),
-    // then row yf + 1 in front of the barrier of step yf.  Row r lives in slot (r + 1) & 3.
-    wf4 hr[3][NIN][NIT];
-    __builtin_amdgcn_s_waitcnt(0);
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-      if ((unsigned)(y_begin - 1 + j) < (unsigned)a.H) issue(y_begin - 1 + j, std::true_type{}, hr[j]);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) fuse(y_begin - 1 + j, (y_begin + j) & 3, hr[j]);
-    if (y_begin + 2 <= y_end && y_begin + 2 < a.H) issue(y_begin + 2, std::true_type{}, hr[0]);
-    lds_barrier();
-    for (int yf = y_begin + 1; yf <= y_end; ++yf) {
-      if (yf + 1 <= y_end) {
-        fuse(yf + 1, (yf + 2) & 3, hr[0]);
-        if (yf + 2 <= y_end && yf + 2 < a.H) issue(yf + 2, std::true_type{}, hr[0]);
-      }
-      lds_barrier();
-    }
-    return;
-  }
+  wf4 raw[NIA][NIN];
   wf4 dwr[9];                                      // depthwise weights of this lane's channel quad
 #pragma unroll
   for (int t = 0; t < 9; ++t) dwr[t] = *reinterpret_cast<const wf4*>(a.dw + t * RC + cs);
   // pointwise weights of output column block `wave` for all RC / 8 channel steps (packed as for bifpn_rows.hip:
   // weights are the A operand, pixels the B operand, so a lane's accumulator is four consecutive channels
   // 16 wave + 4 (lane >> 4) .. + 3 of pixel lane & 15)
-  constexpr int NCB = GEO::NW;
   wf2 bw[K8];
 #pragma unroll
   for (int k8 = 0; k8 < K8; ++k8)
-    bw[k8] = *reinterpret_cast<const wf2*>(a.pw + ((size_t)(k8 * NCB + wave) * 64 + lane) * 2);
+    bw[k8] = *reinterpret_cast<const wf2*>(a.pw + ((size_t)(k8 * NW + wave) * 64 + lane) * 2);
   wf4 b4 = (wf4){0.f, 0.f, 0.f, 0.f};
   if (a.bias) b4 = *reinterpret_cast<const wf4*>(a.bias + wave * 16 + kq * 4);
 
   wf4 s1 = (wf4){0.f, 0.f, 0.f, 0.f}, s2 = s1;
   __builtin_amdgcn_s_waitcnt(0);                   // (the preamble's loads: see bifpn_rows.hip)
-  int slot = y_begin % NSLOT;                      // slot of row yf = y_begin - 1: (yf + 1) % NSLOT
+  int slot = y_begin & 3;                          // slot of row yf = y_begin - 1: (yf + 1) & 3
 
   auto row = [&](int yf, auto next_all_c, auto out_c) __attribute__((always_inline)) {
-    fuse(yf, slot, raw);
-    if (yf + 1 <= y_end && yf + 1 < a.H) issue(yf + 1, next_all_c, raw);
+    if constexpr (NI > 0) {
+      fuse(yf, slot, raw);
+      if (yf + 1 <= y_end && yf + 1 < a.H) issue(yf + 1, next_all_c, raw);
+    }
     const int y = yf - 1;                               // output row whose three ring rows are now complete
-    // slot of row y - 1 = yf - 2, then the slot of the next row
-    const int s_top = HELP ? (slot + 2) & 3 : (slot == 0 ? 1 : (slot == 1 ? 2 : 0));
-    slot = HELP ? (slot + 1) & 3 : s_top;
+    const int s_top = (slot + 2) & 3;                   // slot of row y - 1 = yf - 2
+    slot = (slot + 1) & 3;
     if (!decltype(out_c)::value) return;             // (the two rows above the segment's first output row)
     // the operand buffer of this row: by row parity (next_all_c is true in the half of the unrolled loop that
     // produces the EVEN output rows)
@@ -264,7 +293,7 @@ void bifpn_rows_wg_kernel(const NodeArgs a, int seg_rows, int strips) {
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy) {
         const unsigned char* src = smem + rs_ * kRowB + dsrc;
-        rs_ = HELP ? (rs_ + 1) & 3 : (rs_ == 2 ? 0 : rs_ + 1);
+        rs_ = (rs_ + 1) & 3;
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx)
           d = __builtin_elementwise_fma(*reinterpret_cast<const wf4*>(src + dx * RC * 4), dwr[dy * 3 + dx], d);
@@ -304,10 +333,11 @@ void bifpn_rows_wg_kernel(const NodeArgs a, int seg_rows, int strips) {
   };
   // (segments start on even rows -- the launcher -- so row y_begin - 1 is odd and the rows requested from the first
   //  half of the unrolled body are even: all inputs; from the second half odd: same-level inputs only)
-  if (y_begin - 1 >= 0) issue(y_begin - 1, std::true_type{}, raw);
+  if constexpr (NI > 0)
+    if (y_begin - 1 >= 0) issue(y_begin - 1, std::true_type{}, raw);
   row(y_begin - 1, std::true_type{}, std::false_type{});
   row(y_begin, std::false_type{}, std::false_type{});
-  if (HELP) lds_barrier();                           // pixels 16, 17 of the first three rows are in the ring
+  lds_barrier();                                     // the helpers' share of the first three rows is in the ring
   for (int yf = y_begin + 1; yf <= y_end; yf += 2) {
     row(yf, std::true_type{}, std::true_type{});
     if (yf + 1 <= y_end) row(yf + 1, std::false_type{}, std::true_type{});
@@ -329,8 +359,9 @@ void bifpn_rows_wg_kernel(const NodeArgs a, int seg_rows, int strips) {
     }
   }
   };
-  if (HELP && wave >= GEO::NW) body(std::true_type{});
-  else body(std::false_type{});
+  if (wave >= NW) body(std::integral_constant<int, 2>{});
+  else if (DPH > 0 && (wave & 3) < NH && (wave >> 2) < DPH) body(std::integral_constant<int, 1>{});
+  else body(std::integral_constant<int, 0>{});
 }
 
 // Shapes of the workgroup form (the channel count is checked by the caller, bifpn_rows_eligible): as many output
@@ -339,7 +370,7 @@ bool bifpn_rows_wg_shape_ok(const NodeArgs& a) {
   return (a.Cp == 160 || a.Cp == 88) && a.cout_p == a.Cp && a.cout_p16 == (a.Cp + 15) / 16 * 16;
 }
 
-template <int RC, bool HELP>
+template <int RC, int DPH>
 static int launch_rows_wg_rc(const NodeArgs& a, hipStream_t s) {
   const int strips = (a.W + 15) / 16;
   // Rows per workgroup: a function of the node and of the predictor's time-batch CLASS only (the float partial sums
@@ -361,11 +392,11 @@ static int launch_rows_wg_rc(const NodeArgs& a, hipStream_t s) {
   seg_rows = (seg_rows + 1) & ~1;
   if (seg_rows > a.H) seg_rows = a.H;
   const int segs = (a.H + seg_rows - 1) / seg_rows;
-  const size_t lds = RowWgGeo<RC>::lds_bytes(HELP);
-  const dim3 grid(strips * segs, a.N), block((RowWgGeo<RC>::NW + (HELP ? RowWgGeo<RC>::NH : 0)) * 64);
+  const size_t lds = RowWgGeo<RC>::lds_bytes();
+  const dim3 grid(strips * segs, a.N), block((RowWgGeo<RC>::NW + RowWgGeo<RC>::NH) * 64);
 #define JH_ROWS(NIN, M1, M2, ACT, POOL)                                                                            \
   do {                                                                                                             \
-    auto kern = bifpn_rows_wg_kernel<RC, NIN, M1, M2, ACT, POOL, HELP>;                                            \
+    auto kern = bifpn_rows_wg_kernel<RC, NIN, M1, M2, ACT, POOL, DPH>;                                             \
     static bool big = false;                                                                                       \
     if (!big && lds > 64 * 1024) {                                                                                 \
       JH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                        \
@@ -399,10 +430,14 @@ static int launch_rows_wg_rc(const NodeArgs& a, hipStream_t s) {
 }
 
 int launch_bifpn_rows_wg(const NodeArgs& a, hipStream_t s) {
-  // (both forms give the same bits; JH_NODE_WG_HELP=0: every channel-group wave fuses its own pixels 16, 17)
-  const bool help = JH_ENV_KNOB("JH_NODE_WG_HELP") != 0;
-  if (a.Cp == 88) return help ? launch_rows_wg_rc<88, true>(a, s) : launch_rows_wg_rc<88, false>(a, s);
-  return help ? launch_rows_wg_rc<160, true>(a, s) : launch_rows_wg_rc<160, false>(a, s);
+  // (every form gives the same bits.  JH_NODE_WG_DELEG=1: the helpers also take the whole fusion round of the group
+  //  waves 0, 1 (88 channels) / 0, 1, 4, 5 (160) -- the waves that share a SIMD with a third group wave; measured SLOWER
+  //  at 384 images: 160 channels P3 1.029 -> 1.054 ms, P4 0.284 -> 0.297, 88 channels @40 0.174 -> 0.184: the helpers'
+  //  three rounds arrive late at the row's barrier; with `s_setprio 3` on the helpers P3 1.016, P4 0.288: a wash, and
+  //  raised priority alone costs 3 %)
+  const bool deleg = JH_ENV_KNOB("JH_NODE_WG_DELEG") > 0;
+  if (a.Cp == 88) return deleg ? launch_rows_wg_rc<88, 1>(a, s) : launch_rows_wg_rc<88, 0>(a, s);
+  return deleg ? launch_rows_wg_rc<160, 2>(a, s) : launch_rows_wg_rc<160, 0>(a, s);
 }
 
 }  // namespace jh
