@@ -17,6 +17,8 @@
 // SIMD carries one of each (the wave-role placement the persistent Winograd kernel, conv3d_wino_pw.hip, relies on).
 // The four pairs own four consecutive (strip, segment) items -- the four strips of a 64-pixel row at P3 -- and share
 // nothing but the barrier.
+// Round 6: the producer of the two-input nodes walks its items in two passes (16 quads x 4 pixel slots + 6 quads x 10)
+// instead of one of 22 quads x 2 slots with 20 idle lanes: 7 fusion rounds instead of 9, 30 ring reads instead of 36.
 // What it buys (measured, 384 images): P3 node 0.476 -> 0.430 ms, P4 0.207 -> 0.190, head 0.549 -> 0.447.  NOT the
 // 2 x a concurrent matrix and vector pipe would give: a SIMD issues ONE instruction stream -- while the consumer streams
 // MFMAs the producer of the same SIMD is starved (tools/mfma_valu_coissue.hip: times add, whatever the instruction
@@ -55,11 +57,11 @@ typedef unsigned pu4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void ps_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 }  // namespace
 
-template <int RC, int NIN, int M1, int M2, int ACT, bool POOL>
+template <int RC, int NIN, int M1, int M2, int ACT, bool POOL, int REPACK>
 __global__ __launch_bounds__(kPsPairs * 128) void bifpn_rows_ps_kernel(const NodeArgs a, int seg_rows, int strips,
                                                                         int segs) {
   using GEO = PsGeo<RC>;
-  constexpr int kRQ = GEO::RQ, NSUB = GEO::NSUB, NIT = GEO::NIT, PPL = GEO::PPL, kRSA = GEO::RSA;
+  constexpr int kRQ = GEO::RQ, kRSA = GEO::RSA;
   constexpr int NCB = GEO::NCB, K8 = GEO::K8, kRowB = GEO::ROWB, kOpB = GEO::OPB;
   constexpr int kAtOff = 3 * kRowB, kBiasOff = kAtOff + 2 * kOpB, kPoolOff = kBiasOff + NCB * 16 * 4;
   constexpr int kModes[3] = {FUSE_SAME, M1, M2};
@@ -77,35 +79,6 @@ __global__ __launch_bounds__(kPsPairs * 128) void bifpn_rows_ps_kernel(const Nod
 
   if (wave >= kPsPairs) {
     // ========================================================================================== producer wave
-    const int q = lane % kRQ, sub = lane / kRQ;   // channel quad, pixel slot (0..NSUB-1; NSUB = the idle lanes)
-    const bool act_lane = sub < NSUB;
-    const int c = q * 4;
-    // folded norm + fusion weights of this lane's channel quad: fused = sum_k x_k a_k + B
-    pf4 ak[NIN], bb = (pf4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < NIN; ++k) {
-      float m4[4] = {0.f, 0.f, 0.f, 0.f}, r4[4] = {1.f, 1.f, 1.f, 1.f};
-      if (a.st[k]) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const double* st = a.st[k] + ((size_t)n * RC + c + j) * kStatW;
-          const double mu = exact_read(st) * (double)a.inv_cnt[k];
-          double var = exact_read(st + kLimbs) * (double)a.inv_cnt[k] - mu * mu;
-          if (var < 0.0) var = 0.0;
-          m4[j] = (float)mu;
-          r4[j] = (float)(1.0 / sqrt(var + 1e-5));
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float ak1 = a.w[k] * r4[j];
-        ak[k][j] = ak1;
-        bb[j] += -m4[j] * ak1;
-      }
-    }
-    pf4 dwr[9];                                    // depthwise weights of this lane's channel quad
-#pragma unroll
-    for (int t = 0; t < 9; ++t) dwr[t] = *reinterpret_cast<const pf4*>(a.dw + t * RC + (act_lane ? c : 0));
     __amdgpu_buffer_rsrc_t rs[NIN];
     int rowstep[NIN];                              // bytes per source row of input k
 #pragma unroll
@@ -116,29 +89,76 @@ __global__ __launch_bounds__(kPsPairs * 128) void bifpn_rows_ps_kernel(const Nod
                                                 0x00020000);
       rowstep[k] = (a.W >> sh) * RC * 4;
     }
-    // the NIT items of this lane in a fused row (pixel it * NSUB + sub of the 18): load offsets inside a source row
-    // (bit 31 = outside the image: the buffer load returns 0) and the 0 / 1 mask of the depthwise zero padding
-    int voff[NIN][NIT];
-    float msk[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int px = it * NSUB + sub, ix = ox0 - 1 + px;
-      const bool ok = act_lane && px < kPsPX && (unsigned)ix < (unsigned)a.W;
-      msk[it] = ok ? 1.f : 0.f;
+    // The 18 x RQ (pixel, channel quad) items of a fused row and the 16 x RQ of a depthwise row are walked in PASSES of
+    // NQ quads x 64 / NQ pixel slots.  One pass of all 22 quads leaves 20 lanes idle (2 slots: 9 fusion rounds, 8
+    // depthwise pixels per lane); REPACK (round 6) walks quads 0..15 on 4 slots (5 rounds, 4 pixels) and quads 16..21 on
+    // 10 slots (2 rounds; depthwise on 8 of them, 2 pixels): 7 rounds of loads / FMAs / SiLU instead of 9, 30 ring reads
+    // instead of 36.  Every item is computed exactly as before: same bits.
+    auto pass = [&](auto qb_c, auto nq_c) __attribute__((always_inline)) {
+      constexpr int QB = decltype(qb_c)::value, NQ = decltype(nq_c)::value;
+      constexpr int NSL = 64 / NQ;                               // pixel slots of the fusion
+      constexpr int NITP = (kPsPX + NSL - 1) / NSL;              // fusion items per lane
+      constexpr int DSL = NSL >= 8 ? 8 : (NSL >= 4 ? 4 : (NSL >= 2 ? 2 : 1));   // depthwise slots: a divisor of 16
+      constexpr int PPLP = 16 / DSL;                             // depthwise output pixels per lane
+      struct P {
+        pf4 ak[NIN], bb, dwr[9], raw[NIN][NITP];
+        int voff[NIN][NITP], fdst, dsrc, adst, sub;
+        float msk[NITP];
+        bool act, dact;
+      } st;
+      const int q = lane % NQ;
+      st.sub = lane / NQ;                          // pixel slot (NSL and up: idle lanes)
+      st.act = st.sub < NSL;
+      st.dact = st.sub < DSL;
+      const int c = (QB + q) * 4;
+      // folded norm + fusion weights of this lane's channel quad: fused = sum_k x_k a_k + B
+      st.bb = (pf4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int k = 0; k < NIN; ++k) {
-        const int sh = kModes[k] == FUSE_UP2 ? 1 : (kModes[k] == FUSE_UP4 ? 2 : 0);
-        voff[k][it] = ok ? ((ix >> sh) * RC + c) * 4 : (int)0x80000000;
+        float m4[4] = {0.f, 0.f, 0.f, 0.f}, r4[4] = {1.f, 1.f, 1.f, 1.f};
+        if (a.st[k]) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const double* sp = a.st[k] + ((size_t)n * RC + c + j) * kStatW;
+            const double mu = exact_read(sp) * (double)a.inv_cnt[k];
+            double var = exact_read(sp + kLimbs) * (double)a.inv_cnt[k] - mu * mu;
+            if (var < 0.0) var = 0.0;
+            m4[j] = (float)mu;
+            r4[j] = (float)(1.0 / sqrt(var + 1e-5));
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float ak1 = a.w[k] * r4[j];
+          st.ak[k][j] = ak1;
+          st.bb[j] += -m4[j] * ak1;
+        }
       }
-    }
-    const int fdst = (sub * RC + c) * 4;                          // + it * NSUB pixels (imm) + ring slot
-    const int dsrc = (sub * PPL * RC + c) * 4;                    // + ring slot + tap (imm)
-    const int adst = kAtOff + (sub * PPL * kRSA + c) * 4;         // + operand buffer + pixel (imm)
-    pf4 raw[NIN][NIT];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) st.dwr[t] = *reinterpret_cast<const pf4*>(a.dw + t * RC + c);   // depthwise weights
+      // the items of this lane in a fused row (pixel it * NSL + sub of the 18): load offsets inside a source row
+      // (bit 31 = outside the image: the buffer load returns 0) and the 0 / 1 mask of the depthwise zero padding
+#pragma unroll
+      for (int it = 0; it < NITP; ++it) {
+        const int px = it * NSL + st.sub, ix = ox0 - 1 + px;
+        const bool ok = st.act && px < kPsPX && (unsigned)ix < (unsigned)a.W;
+        st.msk[it] = ok ? 1.f : 0.f;
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) {
+          const int sh = kModes[k] == FUSE_UP2 ? 1 : (kModes[k] == FUSE_UP4 ? 2 : 0);
+          st.voff[k][it] = ok ? ((ix >> sh) * RC + c) * 4 : (int)0x80000000;
+        }
+      }
+      st.fdst = (st.sub * RC + c) * 4;                            // + it * NSL pixels (imm) + ring slot
+      st.dsrc = (st.sub * PPLP * RC + c) * 4;                     // + ring slot + tap (imm)
+      st.adst = kAtOff + (st.sub * PPLP * kRSA + c) * 4;          // + operand buffer + pixel (imm)
+      return st;
+    };
     // (see bifpn_rows.hip: an up-sampled input changes its source row only every 2nd output row; `all_c` is a
     //  compile-time flag because loads under a run-time branch make the compiler's in-order wait counts pessimistic)
-    auto issue = [&](int yf, auto all_c) __attribute__((always_inline)) {       // (yf inside the image)
+    auto issue = [&](auto& st, int yf, auto all_c) __attribute__((always_inline)) {       // (yf inside the image)
       constexpr bool all = decltype(all_c)::value;
+      constexpr int NITP = sizeof(st.msk) / sizeof(float);
       int srow[NIN];
 #pragma unroll
       for (int k = 0; k < NIN; ++k) {
@@ -146,28 +166,30 @@ __global__ __launch_bounds__(kPsPairs * 128) void bifpn_rows_ps_kernel(const Nod
         srow[k] = (yf >> sh) * rowstep[k];
       }
 #pragma unroll
-      for (int it = 0; it < NIT; ++it)
+      for (int it = 0; it < NITP; ++it)
 #pragma unroll
         for (int k = 0; k < NIN; ++k)
           if (all || kModes[k] == FUSE_SAME)
-            raw[k][it] =
-                __builtin_bit_cast(pf4, __builtin_amdgcn_raw_buffer_load_b128(rs[k], voff[k][it], srow[k], 0));
+            st.raw[k][it] =
+                __builtin_bit_cast(pf4, __builtin_amdgcn_raw_buffer_load_b128(rs[k], st.voff[k][it], srow[k], 0));
     };
     // fused + activated row yf -> ring slot (yf + 1) % 3 (zeros outside the image: the depthwise padding)
-    auto fuse = [&](int yf, int slot) __attribute__((always_inline)) {
-      unsigned char* dst = smem + slot * kRowB + fdst;
+    auto fuse = [&](auto& st, auto nsl_c, int yf, int slot) __attribute__((always_inline)) {
+      constexpr int NSL = decltype(nsl_c)::value;
+      constexpr int NITP = sizeof(st.msk) / sizeof(float);
+      unsigned char* dst = smem + slot * kRowB + st.fdst;
       if ((unsigned)yf >= (unsigned)a.H) {                             // (uniform) padding row
 #pragma unroll
-        for (int it = 0; it < NIT; ++it)
-          if (act_lane && it * NSUB + sub < kPsPX)
-            *reinterpret_cast<pf4*>(dst + it * NSUB * RC * 4) = (pf4){0.f, 0.f, 0.f, 0.f};
+        for (int it = 0; it < NITP; ++it)
+          if (st.act && it * NSL + st.sub < kPsPX)
+            *reinterpret_cast<pf4*>(dst + it * NSL * RC * 4) = (pf4){0.f, 0.f, 0.f, 0.f};
         return;
       }
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        pf4 v = bb;
+      for (int it = 0; it < NITP; ++it) {
+        pf4 v = st.bb;
 #pragma unroll
-        for (int k = 0; k < NIN; ++k) v = __builtin_elementwise_fma(raw[k][it], ak[k], v);
+        for (int k = 0; k < NIN; ++k) v = __builtin_elementwise_fma(st.raw[k][it], st.ak[k], v);
         if (ACT == ACT_SILU) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = v[j] * __builtin_amdgcn_rcpf(1.f + __expf(-v[j]));
@@ -175,32 +197,25 @@ __global__ __launch_bounds__(kPsPairs * 128) void bifpn_rows_ps_kernel(const Nod
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
         }
-        if (it == 0 || it == NIT - 1) v *= (pf4){msk[it], msk[it], msk[it], msk[it]};
-        if (act_lane && it * NSUB + sub < kPsPX) *reinterpret_cast<pf4*>(dst + it * NSUB * RC * 4) = v;
+        // (pixels 0 and 17 of a strip at the image border live in the first and the last item)
+        if (it == 0 || it == NITP - 1) v *= (pf4){st.msk[it], st.msk[it], st.msk[it], st.msk[it]};
+        if (st.act && it * NSL + st.sub < kPsPX) *reinterpret_cast<pf4*>(dst + it * NSL * RC * 4) = v;
       }
     };
-    __builtin_amdgcn_s_waitcnt(0);                 // (the preamble's loads: see bifpn_rows.hip)
-    int slot = (y_begin + 3) % 3;                  // slot of row yf = y_begin - 1: (yf + 1) % 3
-    auto row = [&](int yf, auto next_all_c, auto out_c) __attribute__((always_inline)) {
-      fuse(yf, slot);
-      if (yf + 1 <= y_end && yf + 1 < a.H) issue(yf + 1, next_all_c);
-      const int s_top = slot == 0 ? 1 : (slot == 1 ? 2 : 0);          // slot of row y - 1 = (slot + 1) % 3
-      slot = s_top;
-      if (!decltype(out_c)::value) return;           // (the two rows above the segment's first output row)
-      // operand block of this output row: by row parity (next_all_c is true in the half of the unrolled loop that
-      // produces the EVEN output rows)
-      constexpr int kBuf = decltype(next_all_c)::value ? 0 : kOpB;
-      if (act_lane) {
+    // depthwise 3x3 of output row y (ring slot of row y - 1: s_top) -> operand block kBuf
+    auto depthwise = [&](auto& st, auto ppl_c, int s_top, int kBuf) __attribute__((always_inline)) {
+      constexpr int PPLP = decltype(ppl_c)::value;
+      constexpr int PXN = PPLP >= 4 ? 4 : PPLP;
+      if (st.dact) {
         int rs_ = s_top;                                               // ring slot of row y - 1 + dy
         const unsigned char* src[3];
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
-          src[dy] = smem + rs_ * kRowB + dsrc;
+          src[dy] = smem + rs_ * kRowB + st.dsrc;
           rs_ = rs_ == 2 ? 0 : rs_ + 1;
         }
-        constexpr int PXN = PPL >= 4 ? 4 : PPL;
 #pragma unroll
-        for (int part = 0; part < PPL / PXN; ++part) {
+        for (int part = 0; part < PPLP / PXN; ++part) {
           pf4 d[PXN];
 #pragma unroll
           for (int i = 0; i < PXN; ++i) d[i] = (pf4){0.f, 0.f, 0.f, 0.f};
@@ -213,16 +228,52 @@ __global__ __launch_bounds__(kPsPairs * 128) void bifpn_rows_ps_kernel(const Nod
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-              for (int i = 0; i < PXN; ++i) d[i] = __builtin_elementwise_fma(x[i + dx], dwr[dy * 3 + dx], d[i]);
+              for (int i = 0; i < PXN; ++i) d[i] = __builtin_elementwise_fma(x[i + dx], st.dwr[dy * 3 + dx], d[i]);
           }
 #pragma unroll
           for (int i = 0; i < PXN; ++i)
-            *reinterpret_cast<pf4*>(smem + adst + kBuf + (part * PXN + i) * kRSA * 4) = d[i];
+            *reinterpret_cast<pf4*>(smem + st.adst + kBuf + (part * PXN + i) * kRSA * 4) = d[i];
         }
+      }
+    };
+    // REPACK 1: both phases in two passes; 2: the fusion in two passes, the depthwise in one (three inputs: the second
+    // pass's depthwise weights do not fit the registers next to 21 loads in flight)
+    constexpr int QA = REPACK ? 16 : kRQ;          // quads of the first pass; the second takes the rest
+    constexpr int QT = REPACK ? kRQ - 16 : kRQ;    // (not used without REPACK)
+    constexpr int kDSL1 = 64 / kRQ >= 8 ? 8 : (64 / kRQ >= 4 ? 4 : (64 / kRQ >= 2 ? 2 : 1));
+    constexpr int NSLA = 64 / QA, NSLB = 64 / QT;
+    constexpr int DSLA = NSLA >= 8 ? 8 : (NSLA >= 4 ? 4 : (NSLA >= 2 ? 2 : 1));
+    constexpr int DSLB = NSLB >= 8 ? 8 : (NSLB >= 4 ? 4 : (NSLB >= 2 ? 2 : 1));
+    auto pa = pass(std::integral_constant<int, 0>{}, std::integral_constant<int, QA>{});
+    auto pb = pass(std::integral_constant<int, REPACK ? 16 : 0>{}, std::integral_constant<int, QT>{});
+    auto pd = pass(std::integral_constant<int, 0>{}, std::integral_constant<int, kRQ>{});   // (REPACK 2: its depthwise)
+    __builtin_amdgcn_s_waitcnt(0);                 // (the preamble's loads: see bifpn_rows.hip)
+    int slot = (y_begin + 3) % 3;                  // slot of row yf = y_begin - 1: (yf + 1) % 3
+    auto row = [&](int yf, auto next_all_c, auto out_c) __attribute__((always_inline)) {
+      fuse(pa, std::integral_constant<int, NSLA>{}, yf, slot);
+      if (REPACK) fuse(pb, std::integral_constant<int, NSLB>{}, yf, slot);
+      if (yf + 1 <= y_end && yf + 1 < a.H) {
+        issue(pa, yf + 1, next_all_c);
+        if (REPACK) issue(pb, yf + 1, next_all_c);
+      }
+      const int s_top = slot == 0 ? 1 : (slot == 1 ? 2 : 0);          // slot of row y - 1 = (slot + 1) % 3
+      slot = s_top;
+      if (!decltype(out_c)::value) return;           // (the two rows above the segment's first output row)
+      // operand block of this output row: by row parity (next_all_c is true in the half of the unrolled loop that
+      // produces the EVEN output rows)
+      constexpr int kBuf = decltype(next_all_c)::value ? 0 : kOpB;
+      if (REPACK == 2) {
+        depthwise(pd, std::integral_constant<int, 16 / kDSL1>{}, s_top, kBuf);
+      } else {
+        depthwise(pa, std::integral_constant<int, 16 / DSLA>{}, s_top, kBuf);
+        if (REPACK) depthwise(pb, std::integral_constant<int, 16 / DSLB>{}, s_top, kBuf);
       }
       ps_barrier();                                  // this row's operand block is complete; the consumer has left
     };                                               // the other block (it read it before arriving here)
-    if (y_begin - 1 >= 0) issue(y_begin - 1, std::true_type{});
+    if (y_begin - 1 >= 0) {
+      issue(pa, y_begin - 1, std::true_type{});
+      if (REPACK) issue(pb, y_begin - 1, std::true_type{});
+    }
     row(y_begin - 1, std::true_type{}, std::false_type{});
     row(y_begin, std::false_type{}, std::false_type{});
     for (int yf = y_begin + 1; yf <= y_end; yf += 2) {
@@ -353,7 +404,18 @@ int launch_bifpn_rows_ps(const NodeArgs& a, int seg_rows, int strips, int segs, 
   const dim3 grid((unsigned)((long)strips * segs * a.N / kPsPairs)), block(kPsPairs * 128);
 #define JH_PS(NIN, M1, M2, ACT, POOL)                                                                            \
   do {                                                                                                           \
-    auto kern = bifpn_rows_ps_kernel<RC, NIN, M1, M2, ACT, POOL>;                                                \
+    /* (two-input nodes, 384 images: P3 0.432 -> 0.397 ms, def320's 80-pixel level 0.350 -> 0.322.  Three inputs  \
+       stay on the one pass: fully repacked the producer holds 21 loads of a row in flight -- 256 registers +   \
+       72..128 B of scratch; with only the fusion repacked (2) the eight P4 nodes of medium take 2.418 against   \
+       2.378 ms.  JH_NODE_PS_REPACK=0: off, 2 / 3: those two forms for three inputs) */                          \
+    if (JH_ENV_KNOB("JH_NODE_PS_REPACK") == 0 || (NIN == 3 && JH_ENV_KNOB("JH_NODE_PS_REPACK") < 2))             \
+      JH_PS_(NIN, M1, M2, ACT, POOL, 0);                                                                         \
+    else if (NIN == 3 && JH_ENV_KNOB("JH_NODE_PS_REPACK") == 2) JH_PS_(NIN, M1, M2, ACT, POOL, 2);               \
+    else JH_PS_(NIN, M1, M2, ACT, POOL, 1);                                                                      \
+  } while (0)
+#define JH_PS_(NIN, M1, M2, ACT, POOL, REPACK)                                                                   \
+  do {                                                                                                           \
+    auto kern = bifpn_rows_ps_kernel<RC, NIN, M1, M2, ACT, POOL, REPACK>;                                        \
     static bool big = false;                                                                                     \
     if (!big) {                                                                                                  \
       JH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                      \
@@ -378,6 +440,7 @@ int launch_bifpn_rows_ps(const NodeArgs& a, int seg_rows, int strips, int segs, 
     else JH_REQUIRE(false, "producer / consumer node: activation");
   }
 #undef JH_PS
+#undef JH_PS_
   JH_CHECK_HIP(hipGetLastError());
   return 0;
 }
