@@ -45,7 +45,7 @@ struct RowWgGeo {
   static constexpr int OPB = 16 * RSA * 4;         // bytes per operand block
   static constexpr int NH = 2;                     // helper waves (see the kernel)
   static constexpr int NSLOT = 4;                  // ring rows
-  static constexpr size_t lds_bytes() { return (size_t)NSLOT * ROWB + 2 * OPB; }
+  static constexpr size_t lds_bytes() { return (size_t)NSLOT * ROWB + 2 * OPB + 4 * 1024; }   // (+ the helpers' partial sums)
   static_assert(RC % 8 == 0 && NW <= 16, "channel count of the workgroup row-streaming node");
 };
 typedef float wf2 __attribute__((ext_vector_type(2)));
@@ -56,22 +56,31 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 // Helper waves (round 6).  A ring row is 18 pixels x 4 quads = 72 fusion items per channel group: the second fusion
 // round of a group wave carried 8 items on 64 lanes -- loads, FMAs and the two transcendentals of SiLU issued for an
-// eighth of a wave -- and the NW group waves sit unevenly on the four SIMDs (160 channels: 3 / 3 / 2 / 2; 88: 2 / 2 / 1 / 1).
-// So the workgroup has NH = 2 more waves (they land on the SIMDs with the fewest group waves: waves w and w + 4 share a SIMD, tools/wave_simd_probe.hip):
-//   * item 0 of a helper lane: pixels 16, 17 of ALL channel groups (8 NW items over the two helpers),
-//   * items 1 .. DPH (experiment, off: launch_bifpn_rows_wg): the whole 16-pixel fusion round of DPH group waves of the
-//     crowded SIMDs (helper h serves groups h, h + 4, ..), which then do no fusion and issue no global loads (ROLE 1),
-// one row AHEAD of the group waves, so that the row's one barrier orders the helpers' ring writes before the depthwise
-// that reads them; that takes a fourth ring slot (the slot of row r + 1 is still being read as row r - 2 otherwise).
-// The arithmetic of every item is unchanged: every form gives the same bits.
-template <int RC, int NIN, int M1, int M2, int ACT, bool POOL, int DPH>
+// eighth of a wave -- and the NW group waves sit unevenly on the four SIMDs (160 channels: 3 / 3 / 2 / 2; 88: 2 / 2 / 1 / 1;
+// waves w and w + 4 share a SIMD: tools/wave_simd_probe.hip).  So the workgroup has NH = 2 more waves, which land on the
+// SIMDs with the fewest group waves:
+//   * they fuse pixels 16, 17 of ALL channel groups (8 NW items over the two helpers), one row AHEAD of the group
+//     waves, so that the row's one barrier orders their ring writes before the depthwise that reads them; that takes a
+//     fourth ring slot (the slot of row r + 1 is still being read as row r - 2 otherwise).  Same bits as without them.
+//   * KSPLIT: helper h also runs the UPPER half of the channel steps of column block NW - 2 + h -- the MFMAs of the
+//     last group wave of each crowded SIMD (160 channels: 120 / 120 / 80 / 80 MFMAs per row and SIMD become 100 each; 88:
+//     44 / 44 / 22 / 22 become 33 each).  It leaves its partial sums in LDS; the group wave (ROLE 1) adds them one row
+//     later, behind the next row's barrier, and only then finishes that row (bias, statistics, stores).  The sum of the
+//     two halves is not the one chain's sum: the last two column blocks differ in the last bits from the unsplit form
+//     (a function of the node's shape alone, like every other choice of form).
+template <int RC, int NIN, int M1, int M2, int ACT, bool POOL, bool KSPLIT>
 __global__ __launch_bounds__((RowWgGeo<RC>::NW + RowWgGeo<RC>::NH) * 64)
 void bifpn_rows_wg_kernel(const NodeArgs a, int seg_rows, int strips) {
   using GEO = RowWgGeo<RC>;
   constexpr int NSLOT = GEO::NSLOT, NW = GEO::NW, NH = GEO::NH;
   constexpr int K8 = GEO::K8, RSA = GEO::RSA, kRowB = GEO::ROWB, kOpOff = NSLOT * GEO::ROWB, kOpB = GEO::OPB;
   constexpr int kModes[3] = {FUSE_SAME, M1, M2};
-  static_assert(NSLOT == 4 && 4 * (DPH - 1) + NH - 1 < NW, "delegated channel groups");
+  // channel steps of a split column block that stay with its group wave (the even split is the fastest: 160 channels,
+  // P3 node at 384 images, 10 / 8 / 7 / 6 of 20 steps: 0.973 / 1.021 / 0.969 / 0.986 ms, P4 nodes 6.44 / 6.33 / 6.56 / 6.63 ms
+  // per batch; 88 channels: 6, 4, 3, 2 of 11 within 1 %)
+  constexpr int KS = KSPLIT ? (K8 + 1) / 2 : K8;
+  constexpr int kPartOff = kOpOff + 2 * kOpB;      // + (helper, row parity) x 1 KB: the helpers' partial sums
+  static_assert(NSLOT == 4 && NH == 2 && NW >= 4, "helper waves");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -79,11 +88,10 @@ void bifpn_rows_wg_kernel(const NodeArgs a, int seg_rows, int strips) {
   const int ox0 = sx * 16, y_begin = seg * seg_rows, y_end = min(a.H, y_begin + seg_rows);
   // (the roles are instantiations of one body: the role must be a compile-time constant or the channel masks of the
   //  160-channel form stop folding and the group waves' row loop fills with exec-masked regions and spills)
-  // ROLE 0: group wave that fuses its own pixels 0..15; 1: group wave whose ring rows a helper writes; 2: helper
+  // ROLE 0: group wave; 1: group wave whose upper channel steps a helper runs (KSPLIT); 2: helper
   auto body = [&](auto role_c) __attribute__((always_inline)) {
   constexpr int ROLE = decltype(role_c)::value;
-  constexpr int NI = ROLE == 0 ? 1 : (ROLE == 1 ? 0 : 1 + DPH);      // fusion items per lane and row
-  constexpr int NIA = NI > 0 ? NI : 1;
+  constexpr int NI = 1, NIA = 1;                   // fusion items per lane and row
   const int mrow = lane & 15, kq = lane >> 4;
 
   // ---- fusion items of this lane: ring pixel, channel quad ---------------------------------------------------
@@ -92,20 +100,16 @@ void bifpn_rows_wg_kernel(const NodeArgs a, int seg_rows, int strips) {
   bool iok[NIA];
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
-    if (ROLE == 0) {
+    if (ROLE != 2) {
       ipx[i] = lane >> 2;
       ic[i] = wave * 16 + (lane & 3) * 4;
       iok[i] = RC % 16 == 0 || ic[i] < RC;
-    } else if (i == 0) {
+    } else {
       constexpr int per = NW * 8 / NH;
       const int hitem = (wave - NW) * per + lane;                     // (channel group, pixel 16 / 17, quad)
       ipx[i] = 16 + ((hitem >> 2) & 1);
       ic[i] = (hitem >> 3) * 16 + (hitem & 3) * 4;
       iok[i] = lane < per && ic[i] < RC;
-    } else {
-      ipx[i] = lane >> 2;
-      ic[i] = ((wave - NW) + 4 * (i - 1)) * 16 + (lane & 3) * 4;
-      iok[i] = RC % 16 == 0 || ic[i] < RC;
     }
   }
   // folded norm + fusion weights of an item's channel quad: fused = sum_k x_k a_k + B
@@ -211,6 +215,28 @@ void bifpn_rows_wg_kernel(const NodeArgs a, int seg_rows, int strips) {
     // rows y_begin - 1 .. y_begin + 1 before the group waves' first depthwise (the barrier in front of their row loop),
     // then row yf + 1 in front of the barrier of step yf.  Row r lives in slot (r + 1) & 3.
     wf4 ra[NIA][NIN], rb[NIA][NIN];
+    // KSPLIT: the upper channel steps of column block NW - 2 + (wave - NW), weights in registers like a group wave's
+    constexpr int KH = KSPLIT ? K8 - KS : 1;
+    wf2 bwh[KH];
+    if (KSPLIT) {
+#pragma unroll
+      for (int k8 = 0; k8 < KH; ++k8)
+        bwh[k8] = *reinterpret_cast<const wf2*>(a.pw + ((size_t)((KS + k8) * NW + (wave - 2)) * 64 + lane) * 2);
+    }
+    const int ardh = kOpOff + (mrow * RSA) * 4 + kq * 8 + KS * 32;    // + operand buffer + channel step (imm)
+    const int pdst = kPartOff + (wave - NW) * 2048 + lane * 16;       // + row parity x 1 KB
+    auto partial = [&](int y) __attribute__((always_inline)) {       // (behind the barrier that completes row y's block)
+      const int kBuf = (y & 1) ? kOpB : 0;
+      f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+      for (int k8 = 0; k8 < KH; ++k8) {
+        const float2 xc = *reinterpret_cast<const float2*>(smem + ardh + kBuf + k8 * 32);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bwh[k8][0], xc.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(bwh[k8][1], xc.y, acc1, 0, 0, 0);
+      }
+      *reinterpret_cast<wf4*>(smem + pdst + (y & 1) * 1024) =
+          (wf4){acc0[0], acc0[1], acc0[2], acc0[3]} + (wf4){acc1[0], acc1[1], acc1[2], acc1[3]};
+    };
     __builtin_amdgcn_s_waitcnt(0);
     if (y_begin - 1 >= 0) issue(y_begin - 1, std::true_type{}, ra);
     issue(y_begin, std::true_type{}, rb);
@@ -226,7 +252,9 @@ void bifpn_rows_wg_kernel(const NodeArgs a, int seg_rows, int strips) {
         if (yf + 2 <= y_end && yf + 2 < a.H) issue(yf + 2, std::true_type{}, ra);
       }
       lds_barrier();
+      if (KSPLIT) partial(yf - 1);
     }
+    if (KSPLIT) lds_barrier();                         // the last row's partial sums are in LDS
     return;
   }
 
@@ -263,10 +291,13 @@ void bifpn_rows_wg_kernel(const NodeArgs a, int seg_rows, int strips) {
   // pointwise weights of output column block `wave` for all RC / 8 channel steps (packed as for bifpn_rows.hip:
   // weights are the A operand, pixels the B operand, so a lane's accumulator is four consecutive channels
   // 16 wave + 4 (lane >> 4) .. + 3 of pixel lane & 15)
-  wf2 bw[K8];
+  constexpr int KM = ROLE == 1 ? KS : K8;          // (ROLE 1: the upper channel steps are the helper's)
+  wf2 bw[KM];
 #pragma unroll
-  for (int k8 = 0; k8 < K8; ++k8)
+  for (int k8 = 0; k8 < KM; ++k8)
     bw[k8] = *reinterpret_cast<const wf2*>(a.pw + ((size_t)(k8 * NW + wave) * 64 + lane) * 2);
+  const int psrc = kPartOff + (wave - (NW - 2)) * 2048 + lane * 16;     // + row parity x 1 KB (ROLE 1)
+  wf4 plo = (wf4){0.f, 0.f, 0.f, 0.f};             // ROLE 1: this wave's half of the previous row's sums
   wf4 b4 = (wf4){0.f, 0.f, 0.f, 0.f};
   if (a.bias) b4 = *reinterpret_cast<const wf4*>(a.bias + wave * 16 + kq * 4);
 
@@ -274,7 +305,31 @@ void bifpn_rows_wg_kernel(const NodeArgs a, int seg_rows, int strips) {
   __builtin_amdgcn_s_waitcnt(0);                   // (the preamble's loads: see bifpn_rows.hip)
   int slot = y_begin & 3;                          // slot of row yf = y_begin - 1: (yf + 1) & 3
 
-  auto row = [&](int yf, auto next_all_c, auto out_c) __attribute__((always_inline)) {
+  // ---- bias, statistics (in registers across the strip), one 16-byte store: p = the row's sums, even_c = its parity
+  auto finish = [&](const wf4 p, int y, auto even_c) __attribute__((always_inline)) {
+    const wf4 v = p + b4;
+    const wf4 vm = v * (wf4){pm, pm, pm, pm};
+    s1 += vm;
+    s2 = __builtin_elementwise_fma(vm, v, s2);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wu4, v), ry, yoff + y * a.W * a.cout_p * 4, 0, 0);
+    if (POOL) {
+      wf4 hm;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        hm[j] = fmaxf(v[j], __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v[j]), 0xB1, 0xF, 0xF, true)));
+      if (decltype(even_c)::value) {                                      // even output row: keep
+        park = hm;
+      } else {                                                            // odd row: combine, store
+        wf4 pv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pv[j] = fmaxf(park[j], hm[j]);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wu4, pv), rp,
+                                               pbase + (y >> 1) * (a.W >> 1) * a.cout_p * 4, 0, 0);
+      }
+    }
+  };
+
+  auto row = [&](int yf, auto next_all_c, auto out_c, auto fin_c) __attribute__((always_inline)) {
     if constexpr (NI > 0) {
       fuse(yf, slot, raw);
       if (yf + 1 <= y_end && yf + 1 < a.H) issue(yf + 1, next_all_c, raw);
@@ -304,43 +359,51 @@ void bifpn_rows_wg_kernel(const NodeArgs a, int seg_rows, int strips) {
     // ---- pointwise 1x1: 16 output channels x 16 pixels x RC channels on the matrix cores --------------------
     f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
 #pragma unroll
-    for (int k8 = 0; k8 < K8; ++k8) {
+    for (int k8 = 0; k8 < KM; ++k8) {
       const float2 xc = *reinterpret_cast<const float2*>(smem + ard + kBuf + k8 * 32);
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[k8][0], xc.x, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[k8][1], xc.y, acc1, 0, 0, 0);
     }
-    // ---- bias, statistics (in registers across the strip), one 16-byte store ---------------------------------
-    const wf4 v = ((wf4){acc0[0], acc0[1], acc0[2], acc0[3]} + (wf4){acc1[0], acc1[1], acc1[2], acc1[3]}) + b4;
-    const wf4 vm = v * (wf4){pm, pm, pm, pm};
-    s1 += vm;
-    s2 = __builtin_elementwise_fma(vm, v, s2);
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wu4, v), ry, yoff + y * a.W * a.cout_p * 4, 0, 0);
-    if (POOL) {
-      wf4 hm;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        hm[j] = fmaxf(v[j], __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v[j]), 0xB1, 0xF, 0xF, true)));
-      if (decltype(next_all_c)::value) {                                  // even output row: keep
-        park = hm;
-      } else {                                                            // odd row: combine, store
-        wf4 pv;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) pv[j] = fmaxf(park[j], hm[j]);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wu4, pv), rp,
-                                               pbase + (y >> 1) * (a.W >> 1) * a.cout_p * 4, 0, 0);
+    const wf4 p = (wf4){acc0[0], acc0[1], acc0[2], acc0[3]} + (wf4){acc1[0], acc1[1], acc1[2], acc1[3]};
+    if constexpr (ROLE == 1) {
+      // (the helper's half of row y - 1 was complete before the barrier above; that row is finished now, this row's
+      //  half waits in registers for the next barrier)
+      if constexpr (decltype(fin_c)::value) {           // (not in the segment's first row: a compile-time flag, the
+        const wf4 phi = *reinterpret_cast<const wf4*>(smem + psrc + (decltype(next_all_c)::value ? 1024 : 0));   // loop is peeled)
+        finish(plo + phi, y - 1, std::integral_constant<bool, !decltype(next_all_c)::value>{});
       }
+      plo = p;
+    } else {
+      finish(p, y, next_all_c);
     }
   };
   // (segments start on even rows -- the launcher -- so row y_begin - 1 is odd and the rows requested from the first
   //  half of the unrolled body are even: all inputs; from the second half odd: same-level inputs only)
   if constexpr (NI > 0)
     if (y_begin - 1 >= 0) issue(y_begin - 1, std::true_type{}, raw);
-  row(y_begin - 1, std::true_type{}, std::false_type{});
-  row(y_begin, std::false_type{}, std::false_type{});
+  row(y_begin - 1, std::true_type{}, std::false_type{}, std::false_type{});
+  row(y_begin, std::false_type{}, std::false_type{}, std::false_type{});
   lds_barrier();                                     // the helpers' share of the first three rows is in the ring
-  for (int yf = y_begin + 1; yf <= y_end; yf += 2) {
-    row(yf, std::true_type{}, std::true_type{});
-    if (yf + 1 <= y_end) row(yf + 1, std::false_type{}, std::true_type{});
+  if constexpr (ROLE == 1) {
+    row(y_begin + 1, std::true_type{}, std::true_type{}, std::false_type{});
+    for (int yf = y_begin + 2; yf <= y_end; yf += 2) {
+      row(yf, std::false_type{}, std::true_type{}, std::true_type{});
+      if (yf + 1 <= y_end) row(yf + 1, std::true_type{}, std::true_type{}, std::true_type{});
+    }
+  } else {
+    for (int yf = y_begin + 1; yf <= y_end; yf += 2) {
+      row(yf, std::true_type{}, std::true_type{}, std::false_type{});
+      if (yf + 1 <= y_end) row(yf + 1, std::false_type{}, std::true_type{}, std::false_type{});
+    }
+  }
+  if (KSPLIT) {
+    lds_barrier();                                   // the helpers' sums of the last row
+    if constexpr (ROLE == 1) {
+      // (the pooled output needs an even height, so the last row is odd whenever its parity matters)
+      const int y = y_end - 1;
+      const wf4 phi = *reinterpret_cast<const wf4*>(smem + psrc + (y & 1) * 1024);
+      finish(plo + phi, y, std::false_type{});
+    }
   }
   if (a.stats) {
     // sum over the 16 pixel lanes of a DPP row: xor 1, xor 2 (quad permutes), half-row mirror, row mirror
@@ -360,7 +423,7 @@ void bifpn_rows_wg_kernel(const NodeArgs a, int seg_rows, int strips) {
   }
   };
   if (wave >= NW) body(std::integral_constant<int, 2>{});
-  else if (DPH > 0 && (wave & 3) < NH && (wave >> 2) < DPH) body(std::integral_constant<int, 1>{});
+  else if (KSPLIT && wave >= NW - 2) body(std::integral_constant<int, 1>{});
   else body(std::integral_constant<int, 0>{});
 }
 
@@ -370,7 +433,7 @@ bool bifpn_rows_wg_shape_ok(const NodeArgs& a) {
   return (a.Cp == 160 || a.Cp == 88) && a.cout_p == a.Cp && a.cout_p16 == (a.Cp + 15) / 16 * 16;
 }
 
-template <int RC, int DPH>
+template <int RC, bool KSPLIT>
 static int launch_rows_wg_rc(const NodeArgs& a, hipStream_t s) {
   const int strips = (a.W + 15) / 16;
   // Rows per workgroup: a function of the node and of the predictor's time-batch CLASS only (the float partial sums
@@ -396,7 +459,7 @@ static int launch_rows_wg_rc(const NodeArgs& a, hipStream_t s) {
   const dim3 grid(strips * segs, a.N), block((RowWgGeo<RC>::NW + RowWgGeo<RC>::NH) * 64);
 #define JH_ROWS(NIN, M1, M2, ACT, POOL)                                                                            \
   do {                                                                                                             \
-    auto kern = bifpn_rows_wg_kernel<RC, NIN, M1, M2, ACT, POOL, DPH>;                                             \
+    auto kern = bifpn_rows_wg_kernel<RC, NIN, M1, M2, ACT, POOL, KSPLIT>;                                          \
     static bool big = false;                                                                                       \
     if (!big && lds > 64 * 1024) {                                                                                 \
       JH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                        \
@@ -430,14 +493,10 @@ static int launch_rows_wg_rc(const NodeArgs& a, hipStream_t s) {
 }
 
 int launch_bifpn_rows_wg(const NodeArgs& a, hipStream_t s) {
-  // (every form gives the same bits.  JH_NODE_WG_DELEG=1: the helpers also take the whole fusion round of the group
-  //  waves 0, 1 (88 channels) / 0, 1, 4, 5 (160) -- the waves that share a SIMD with a third group wave; measured SLOWER
-  //  at 384 images: 160 channels P3 1.029 -> 1.054 ms, P4 0.284 -> 0.297, 88 channels @40 0.174 -> 0.184: the helpers'
-  //  three rounds arrive late at the row's barrier; with `s_setprio 3` on the helpers P3 1.016, P4 0.288: a wash, and
-  //  raised priority alone costs 3 %)
-  const bool deleg = JH_ENV_KNOB("JH_NODE_WG_DELEG") > 0;
-  if (a.Cp == 88) return deleg ? launch_rows_wg_rc<88, 1>(a, s) : launch_rows_wg_rc<88, 0>(a, s);
-  return deleg ? launch_rows_wg_rc<160, 2>(a, s) : launch_rows_wg_rc<160, 0>(a, s);
+  // (JH_NODE_WG_KSPLIT=0: the helper waves only fuse pixels 16, 17 -- the form whose bits equal the helper-less kernel's)
+  const bool ks = JH_ENV_KNOB("JH_NODE_WG_KSPLIT") != 0;
+  if (a.Cp == 88) return ks ? launch_rows_wg_rc<88, true>(a, s) : launch_rows_wg_rc<88, false>(a, s);
+  return ks ? launch_rows_wg_rc<160, true>(a, s) : launch_rows_wg_rc<160, false>(a, s);
 }
 
 }  // namespace jh
