@@ -16,7 +16,8 @@
 //     (9 ring reads, 9 packed FMAs), RC / 8 operand reads + RC / 4 MFMAs (two accumulators: even / odd channel
 //     pairs), bias + statistics + one 16-byte store; the 2 x 2 max-pooled output is carried in registers between the
 //     two halves of the unrolled row loop, so every variant can write it.
-// One workgroup (10 + 2 waves at 160 channels, <= 168 registers) per CU; 67 KB of LDS (four ring rows).
+// One workgroup (10 + 2 waves at 160 channels, <= 168 registers) per CU; 71 KB of LDS (four ring rows, two operand blocks,
+// the helpers' partial sums).
 //
 // Also (round 4, single-frame latency of the medium / large models):
 //   * 88 channels = 5.5 channel groups: six waves, the last one's quads 2, 3 and output channels 88..95 masked.  At
