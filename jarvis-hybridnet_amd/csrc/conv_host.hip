@@ -232,6 +232,14 @@ int launch_conv(const ConvDesc& d, const ConvWeights& w, const Act& x, const Act
     if (d.k == 3 && d.stride == 1 && d.ostride == 1 && a.Wout > 16 && a.Wout <= 20 && a.Hout <= 22 &&
         !d.latency_class && JH_ENV_KNOB("JH_CONV_W20") != 0)
       return conv_launch_2d_k3_w20(a, nr, std::max(budget, (size_t)64 * 1024), s);
+    // (the same for the other layers of the default geometry that leave the 8 x 16 tiles half empty: 5 x 5 on 40-pixel
+    //  rows, 3 x 3 stride 2 onto 20 x 20; JH_CONV_W40=0 switches both off)
+    if (!d.latency_class && d.ostride == 1 && JH_ENV_KNOB("JH_CONV_W40") != 0) {
+      if (d.k == 5 && d.stride <= 2 && a.Wout > 32 && a.Wout <= 40)
+        return conv_launch_2d_k5_w40(a, d.stride, nr, std::max(budget, (size_t)64 * 1024), s);
+      if (d.k == 3 && d.stride == 2 && a.Wout > 16 && a.Wout <= 20 && a.Hout <= 22)
+        return conv_launch_2d_k3s2_w20(a, nr, std::max(budget, (size_t)96 * 1024), s);
+    }
     if (d.k == 3 && d.stride <= 2) return conv_launch_2d_k3(a, d.stride, nr, small, budget, s);
     if (d.k == 5 && d.stride <= 2) return conv_launch_2d_k5(a, d.stride, nr, small, budget, s);
   } else {

@@ -797,6 +797,8 @@ int conv_launch_2d_k2(const ConvArgs& a, int nr, int small, size_t budget, hipSt
 int conv_launch_2d_k3(const ConvArgs& a, int stride, int nr, int small, size_t budget, hipStream_t s);
 int conv_launch_2d_k3_w20(const ConvArgs& a, int nr, size_t budget, hipStream_t s);
 int conv_launch_2d_k5(const ConvArgs& a, int stride, int nr, int small, size_t budget, hipStream_t s);
+int conv_launch_2d_k5_w40(const ConvArgs& a, int stride, int nr, size_t budget, hipStream_t s);
+int conv_launch_2d_k3s2_w20(const ConvArgs& a, int nr, size_t budget, hipStream_t s);
 int conv_launch_2d_big(const ConvArgs& a, int k, int stride, int nr, size_t budget, hipStream_t s);
 int conv_launch_3d_k1(const ConvArgs& a, int nr, int small, size_t budget, hipStream_t s);
 int conv_launch_3d_k2s2(const ConvArgs& a, int nr, int small, size_t budget, hipStream_t s);

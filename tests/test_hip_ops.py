@@ -53,6 +53,9 @@ CONV2D = [  # k, stride, cin, cout, H, W, bias, norm_act
     # 3 x 3 stride-1 layers on images 17..20 wide, at most 22 high: one whole-image tile of 23 x 20 pixel slots
     (3, 1, 80, 480, 20, 20, False, 2), (3, 1, 24, 40, 22, 17, True, -1), (3, 1, 16, 16, 9, 20, False, 0),
     (3, 1, 40, 56, 23, 20, False, 0),     # (23 rows: past the whole-image tile's reach -> the 8 x 16 tiles)
+    # 5 x 5 layers on rows of 33..40 pixels (8 x 40 tiles) and 3 x 3 stride-2 layers onto 17..20 x <= 22 (the 23 x 20 tile)
+    (5, 1, 40, 240, 40, 40, False, 2), (5, 2, 24, 144, 80, 80, False, 2), (5, 1, 16, 32, 36, 38, True, -1),
+    (5, 2, 8, 16, 70, 66, True, 0), (3, 2, 40, 240, 40, 40, False, 2), (3, 2, 16, 48, 44, 38, False, 0),
     # few-channel pointwise layers straight from registers (csrc/conv_pw_direct.hip): K <= 48, 1 / 4 / 6 column blocks
     (1, 1, 16, 8, 64, 64, False, 2), (1, 1, 48, 16, 32, 32, False, 0), (1, 1, 16, 56, 32, 32, True, 0),
     (1, 1, 24, 56, 16, 16, True, -1), (1, 1, 24, 88, 16, 32, True, 0), (1, 1, 40, 88, 20, 20, True, 0),
