@@ -2,11 +2,13 @@
 counts, frame sizes, bounding boxes, ROI / spacing pairs and CenterDetect sizes nobody wrote a fixture for.  A case
 passes when validity agrees, the centre arg-max of every camera agrees, and -- on frames whose integer path (truncated
 3D centre, crop centres, gather indices) equals the host oracle's -- the 3D keypoints agree to 1e-3 mm x spacing / 2
-(the north-star bar at the BASELINE configs' spacing of 2 mm, expressed in coarse voxels).  The
+(the north-star bar at the BASELINE configs' spacing of 2 mm, expressed in coarse voxels), or, for a joint that is
+ill-conditioned in the reference's own float32 arithmetic, to twice the distance between the restatement run with
+torch's oneDNN and with its native convolutions (same weights, same frame).  The
 reference truncates a float32-SVD result to integers (jarvis3D.py:161-166,183); where the oracle's own float value
 lies closer to an integer boundary than the two triangulations differ, its integer is a coin flip (DESIGN.md section
 1): such frames are counted and only required to have float centres that agree.
-    python tools/config_sweep.py [n_cases] [seed] [sizes, e.g. large,medium]"""
+    python tools/config_sweep.py [n_cases] [seed] [sizes, e.g. large,medium]      (JH_SWEEP_ONLY=i: only case i of that sweep)"""
 import os
 import random
 import sys
@@ -55,6 +57,8 @@ for case in range(n_cases):
     T = rng.choice([1, 1, 2, 8])
     size = rng.choice(SIZES)      # (medium: the 88-channel pyramid, 32-channel stem; large: 160 channels)
     desc = dict(C=C, J=J, bbox=bbox, center=center, spacing=spacing, G=G, W=W, H=H, focal=focal, T=T, size=size)
+    if os.environ.get("JH_SWEEP_ONLY") not in (None, str(case)):      # (one case of a sweep again: same draws)
+        continue
     try:
         calib = S.ring_calibration(C, W, H, focal)
         sd_c = S.efficienttrack_weights(size, 1, 100 + case)
@@ -75,7 +79,7 @@ for case in range(n_cases):
             torch.cuda.synchronize()
             got = [(p[t:t + 1], c[t:t + 1]) if int(v[t]) else (None, None) for t in range(T)]
         torch.cuda.synchronize()
-        worst, flips_total, coin, worst_noise, worst_solver = 0.0, 0, 0, 0.0, 0.0
+        worst, flips_total, coin, worst_noise, worst_solver, noisy = 0.0, 0, 0, 0.0, 0.0, 0
         dbg = {k: v.cpu() for k, v in pred.native(H, W, time_batch=T).debug("cuda").items()}
         for t in range(T):
             inter = {}
@@ -149,14 +153,33 @@ for case in range(n_cases):
                 e = (pts.cpu() - rp).abs().max(dim=-1)[0][0]
                 bars = bar * torch.clamp(0.02 / rc[0].clamp_min(1e-6), min=1.0)
                 if bool((e >= bars).any()):
+                    # A joint over the bar: is it ill-conditioned in the REFERENCE's own arithmetic?  The same
+                    # restatement, same weights and frame, with torch's other float32 convolution backend (native
+                    # instead of oneDNN): where the reference moves by d_j between its own two implementations, the
+                    # library may be 2 d_j from either (seen: weak joints -- confidence 0.012 .. 0.03 -- of the large
+                    # model on 3-camera rigs: 3.4e-3 mm backend to backend, 5.4e-3 mm library to oneDNN).
+                    torch.backends.mkldnn.enabled = False
+                    try:
+                        with torch.no_grad():
+                            rp2, _ = O.predictor3d_forward(sd_c, sd_h, frames[t], *calib, center_size=center, bbox=bbox,
+                                                           roi_cube_size=roi, grid_spacing=spacing, mean=S.MEAN,
+                                                           std=S.STD, chunk=5, center_model=size, kp_model=size)
+                    finally:
+                        torch.backends.mkldnn.enabled = True
+                    own = (rp2 - rp).abs().max(dim=-1)[0][0] if rp2 is not None else torch.zeros_like(e)
                     print("   per-joint error (mm):", [round(float(x), 5) for x in e], "\n   confidences:",
-                          [round(float(x), 4) for x in rc[0]], flush=True)
+                          [round(float(x), 4) for x in rc[0]], "\n   reference, oneDNN vs native convolutions (mm):",
+                          [round(float(x), 5) for x in own], flush=True)
+                    bars = torch.maximum(bars, 2.0 * own)
+                    noisy += int((e >= bar * torch.clamp(0.02 / rc[0].clamp_min(1e-6), min=1.0)).sum())
                 assert bool((e < bars).all()), "frame %d: %.3g mm off (bar %.3g mm at spacing %d)" % (t, err, bar, spacing)
                 err = float((e / bars).max()) * bar
                 worst = max(worst, err / bar)
         print("ok   %s  worst %.2f of the bar on flip-free frames, %d host index flips, %d truncation coin flips (reference's "
-              "fp32 SVD up to %.2e mm from the fp64 triangulation; library %.1e mm from the exact solution of its float32 system)"
-              % (desc, worst, flips_total, coin, worst_noise, worst_solver), flush=True)
+              "fp32 SVD up to %.2e mm from the fp64 triangulation; library %.1e mm from the exact solution of its float32 system)%s"
+              % (desc, worst, flips_total, coin, worst_noise, worst_solver,
+                 "; %d joint(s) over the plain bar but within 2x the reference's own oneDNN-vs-native distance" % noisy
+                 if noisy else ""), flush=True)
         del pred
     except Exception as e:          # noqa: BLE001 -- the sweep reports every failing configuration
         bad += 1
