@@ -218,10 +218,8 @@ __global__ __launch_bounds__(512, 6) void bifpn_node_kernel(const NodeArgs a) {
           }
           if (!(a.abl & 1) && a.act == ACT_SILU) {
             // x * sigmoid(x) with the hardware exp2 / reciprocal (about 1e-7 relative error)
-            const nf2 el = (nf2){__expf(-lo.x), __expf(-lo.y)} + (nf2){1.f, 1.f};
-            const nf2 eh = (nf2){__expf(-hi.x), __expf(-hi.y)} + (nf2){1.f, 1.f};
-            lo *= (nf2){__builtin_amdgcn_rcpf(el.x), __builtin_amdgcn_rcpf(el.y)};
-            hi *= (nf2){__builtin_amdgcn_rcpf(eh.x), __builtin_amdgcn_rcpf(eh.y)};
+            lo = (nf2){silu_fast(lo.x), silu_fast(lo.y)};
+            hi = (nf2){silu_fast(hi.x), silu_fast(hi.y)};
           } else if (!(a.abl & 1) && a.act == ACT_RELU) {
             lo = __builtin_elementwise_max(lo, (nf2){0.f, 0.f});
             hi = __builtin_elementwise_max(hi, (nf2){0.f, 0.f});

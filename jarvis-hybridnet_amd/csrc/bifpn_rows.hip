@@ -217,7 +217,7 @@ void bifpn_rows_kernel(const NodeArgs a, int seg_rows, int strips) {
       for (int k = 0; k < NIN; ++k) v = __builtin_elementwise_fma(raw[k][it], ak[k], v);
       if (ACT == ACT_SILU) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = v[j] * __builtin_amdgcn_rcpf(1.f + __expf(-v[j]));
+        for (int j = 0; j < 4; ++j) v[j] = silu_fast(v[j]);
       } else if (ACT == ACT_RELU) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(kPsPairs * 128) void bifpn_rows_ps_kernel(const Nod
         for (int k = 0; k < NIN; ++k) v = __builtin_elementwise_fma(st.raw[k][it], st.ak[k], v);
         if (ACT == ACT_SILU) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = v[j] * __builtin_amdgcn_rcpf(1.f + __expf(-v[j]));
+          for (int j = 0; j < 4; ++j) v[j] = silu_fast(v[j]);
         } else if (ACT == ACT_RELU) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);

@@ -340,6 +340,9 @@ __device__ __forceinline__ double sum_xor32(double s) {
 }
 // x * sigmoid(x) with the hardware exp2 and reciprocal (about 1e-7 relative error).  `__fdividef` is a
 // full IEEE division under this build's flags (v_div_scale / v_div_fmas / v_div_fixup: ten instructions).
+// x * sigmoid(x) with the hardware exp2 / reciprocal (about 1e-7 relative error).  (Round 6: v / (1 + expf(-v)) in every
+// kernel instead moves the 3D keypoints of ill-conditioned joints as much as any other reordering of the float32
+// arithmetic does -- not closer to the float64 answer: HISTORY round-6 item 31.)
 __device__ __forceinline__ float silu_fast(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
 #endif
 

